@@ -1,0 +1,94 @@
+/*
+ * sdrx_oracle.h -- CPU restatement of the sdrx channelizer hot path (TEST INFRASTRUCTURE).
+ *
+ * This is the parity oracle for the MI355X implementation in sdrx_amd/.  It is
+ * NOT part of the product: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product path (libsdrxgpu.so) never links,
+ * loads or falls back to anything in oracle/.
+ *
+ * Every function restates, in plain C99 with the same operation order as the
+ * reference's portable (non-AVX2) code path, one piece of johanhedin/sdrx; the
+ * reference file:line it follows is cited next to each function in
+ * sdrx_oracle.c.  Pinning: oracle/gen_fixtures.py compiles the reference's own
+ * header-only classes (oracle/ref_driver.cpp, built into oracle/_ref/) and
+ * checks this restatement against them bit-for-bit (portable build) before it
+ * writes the golden vectors under tests/golden/.
+ *
+ * Data layout everywhere: IQ = interleaved {re, im} float32 (reference
+ * src/iqsample.hpp:26, std::complex<float>).
+ */
+#ifndef SDRX_ORACLE_H
+#define SDRX_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- translator table (reference src/sdrx.cpp:1682-1690) ---- */
+void sdrx_oracle_make_translator(int N, int z, int ch_offset, float *out_iq /* 2*N floats */);
+
+/* ---- MSD: multi-stage translating down sampler (reference src/msd.hpp) ---- */
+typedef struct sdrx_oracle_msd sdrx_oracle_msd;
+
+sdrx_oracle_msd *sdrx_oracle_msd_create(const float *translator_iq, size_t n_translator,
+                                        int n_stages, const uint32_t *m, const uint32_t *n_taps,
+                                        const float *const *taps, int use_ftfir);
+sdrx_oracle_msd *sdrx_oracle_msd_clone(const sdrx_oracle_msd *src);
+size_t sdrx_oracle_msd_m(const sdrx_oracle_msd *msd);
+void sdrx_oracle_msd_decimate(sdrx_oracle_msd *msd, const float *in_iq, size_t in_len,
+                              float *out_iq, size_t *out_len);
+void sdrx_oracle_msd_destroy(sdrx_oracle_msd *msd);
+
+/* ---- AGC / LfAGC (reference src/agc.hpp) ---- */
+typedef struct {
+    float attack, decay, reference, min_gain, max_gain, alpha, gain, power;
+    int   active; /* LfAGC only */
+} sdrx_oracle_agc;
+
+void  sdrx_oracle_agc_init(sdrx_oracle_agc *a, float attack, float decay, float reference,
+                           float max_gain, float alpha);
+void  sdrx_oracle_lfagc_init(sdrx_oracle_agc *a, float attack, float decay, float reference,
+                             float max_gain, float alpha);
+void  sdrx_oracle_agc_set_max_gain(sdrx_oracle_agc *a, float max_gain);
+/* sdrx's per-channel set-up, reference src/sdrx.cpp:1702-1710 */
+void  sdrx_oracle_agc_init_sdrx(sdrx_oracle_agc *agc, sdrx_oracle_agc *agc_lf, int use_lf_agc);
+void  sdrx_oracle_agc_adjust(sdrx_oracle_agc *a, const float *in_iq, size_t n, float *out_iq);
+void  sdrx_oracle_lfagc_adjust(sdrx_oracle_agc *a, const float *in, size_t n, float *out);
+
+/* ---- AM demodulator (reference src/sdrx.cpp:178-180) ---- */
+void  sdrx_oracle_demod_am(const float *in_iq, size_t n, float *out);
+
+/* ---- FIR (reference src/fir.hpp:79-127) ---- */
+typedef struct sdrx_oracle_fir sdrx_oracle_fir;
+sdrx_oracle_fir *sdrx_oracle_fir_create(const float *c, unsigned n);
+void  sdrx_oracle_fir_set_gain(sdrx_oracle_fir *f, float gain_db);
+void  sdrx_oracle_fir_filter(sdrx_oracle_fir *f, const float *in, unsigned in_len, float *out);
+void  sdrx_oracle_fir_destroy(sdrx_oracle_fir *f);
+
+/* ---- channel bank: the data_cb loop + the per-sample part of alsa_write_cb
+ *      (reference src/sdrx.cpp:327-346 and 455-463) over n channels ---- */
+typedef struct sdrx_oracle_bank sdrx_oracle_bank;
+sdrx_oracle_bank *sdrx_oracle_bank_create(int n_channels, const float *const *translators_iq,
+                                          const size_t *n_translator, int n_stages,
+                                          const uint32_t *m, const uint32_t *n_taps,
+                                          const float *const *taps, int use_ftfir, int use_lf_agc);
+/* iq_out[ch*out_stride + i], audio_out[ch*out_stride + i]; either may be NULL.
+ * threads <= 1: serial loop over channels (reference default, sdrx.cpp:342-345);
+ * threads  > 1: channels split over that many OpenMP threads (models -t / ds.hpp). */
+void sdrx_oracle_bank_process(sdrx_oracle_bank *b, const float *in_iq, size_t in_len,
+                              float *iq_out, float *audio_out, size_t out_stride,
+                              size_t *out_len, int threads);
+void sdrx_oracle_bank_destroy(sdrx_oracle_bank *b);
+
+/* ---- synthetic IQ generator (ours; not a reference function) ---- */
+void sdrx_oracle_synth_iq(uint64_t seed, uint64_t n_start, size_t n, float noise_amp,
+                          int n_carriers, const float *const *carrier_tables_iq, int N,
+                          const float *carrier_amp, uint32_t tri_period, float *out_iq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
