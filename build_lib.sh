@@ -1,0 +1,7 @@
+#!/bin/bash
+# Build libsdrxgpu.so (gfx950 only) in-tree.  Usage: ./build_lib.sh [extra hipcc flags]
+set -e
+cd "$(dirname "$0")"
+mkdir -p sdrx_amd/lib
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fno-slp-vectorize "$@" \
+    -o sdrx_amd/lib/libsdrxgpu.so sdrx_amd/csrc/sdrxgpu.hip

