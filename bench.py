@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the sdrx channelizer hot path on MI355X.
+
+A "step" = one 32 ms block of synthetic 10 MS/s IQ (320 000 complex<float>, already resident in
+HBM) through every channel of this GPU's bank: NCO mixer -> 4-stage FIR decimation -> IF-AGC ->
+AM envelope (-> LF-AGC), i.e. the reference's data_cb channel loop (src/sdrx.cpp:327-346) plus
+alsa_write_cb's per-sample lines (455-463).  Metric (BASELINE.json): IQ Msamples/s ingested x
+channels demodulated = million channel-samples per second, whole job.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--channels C]
+
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU: channels shard
+across ranks (weak scaling, C channel instances per GPU, no data-path collective); rank 0 owns the
+IQ stream and each step's block reaches the other GPUs by one RCCL broadcast (the only traffic
+over xGMI, 2.56 MB per 32 ms of signal).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch  # first: libsdrxgpu then binds to the HIP runtime torch ships (one runtime per process)
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from sdrx_amd import bank as sb  # noqa: E402
+from sdrx_amd import chains, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def algorithmic_bytes_per_channel_sample(m_total: int) -> float:
+    """8 B read (one complex<float> in) + (8 + 4)/M B written (decimated IQ + audio)."""
+    return 8.0 + 12.0 / m_total
+
+
+def cpu_baseline(chain, seconds=12.0):
+    """Reference CPU path timed on this box's host cores on a bounded sample of the same workload.
+
+    Uses the compiled reference (oracle/_ref, kind 'reference') when that build travelled here, else
+    the oracle's -O3 build of the C restatement (kind 'port').  This is the ONLY place bench.py touches oracle/."""
+    from oracle import ffi
+    kind = "port"
+    lib = None
+    if ffi.have_ref() and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsdrx_ref_avx2.so")):
+        try:
+            lib = ffi.load("ref_avx2")
+            kind = "reference"
+        except OSError:
+            lib = None
+    if lib is None:
+        ffi.build(ref=False)
+        lib = ffi.load("oracle_fast")
+    n_thr = max(1, min(len(os.sched_getaffinity(0)), 64))
+    n_ch = 16 * n_thr
+    offs = chains.offsets_cycled(n_ch, chain.N)
+    hlp = ffi.load("oracle") if kind == "port" else lib
+    tabs = [hlp.make_translator(chain.N, chain.z, o) if o else None for o in offs]
+    x = synth.synth_iq(1, 0, chain.block_len, 0.25)
+
+    def run(threads, n_channels, budget):
+        b = lib.bank(tabs[:n_channels], chain.stage_tuples())
+        b.process(x, threads=threads)           # warm-up block
+        t0 = time.perf_counter()
+        blocks = 0
+        while True:
+            b.process(x, threads=threads)
+            blocks += 1
+            if time.perf_counter() - t0 >= budget and blocks >= 2:
+                break
+        dt = time.perf_counter() - t0
+        return n_channels * chain.block_len * blocks / dt, blocks
+
+    multi, nb_m = run(n_thr, n_ch, seconds * 0.6)
+    single, nb_s = run(1, 16, seconds * 0.4)
+    return {
+        "value": multi / 1e6, "unit": "Mch-samples/s", "cores": n_thr, "kind": kind,
+        "sample": f"{n_ch} channels x {nb_m} blocks of {chain.block_len} samples, one thread per channel range "
+                  f"(reference -t/DS model); single thread on 16 channels x {nb_s} blocks: {single / 1e6:.1f} Mch-samples/s",
+        "single_core_value": single / 1e6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=10000, help="channel instances per GPU")
+    ap.add_argument("--rate", default="10")
+    ap.add_argument("--block-hint", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ch = chains.chain(args.rate)
+    n_ch = args.channels
+    # this rank's shard of the job's channel list (instances cycle through all N distinct offsets; never deduplicated)
+    offs_all = chains.offsets_cycled(n_ch * world, ch.N)
+    offs = offs_all[rank * n_ch:(rank + 1) * n_ch]
+    tabs = sb.translators_for(ch, offs)
+    stream = torch.cuda.current_stream().cuda_stream
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, stream=stream, block_hint=args.block_hint)
+
+    # synthetic IQ stream: a ring of distinct 32 ms blocks in HBM on rank 0 (uniform noise + 2 AM carriers)
+    n_ring = 8
+    L = ch.block_len
+    blk = torch.empty(L, 2, dtype=torch.float32, device="cuda")
+    ring = None
+    if rank == 0:
+        car_offs = [5, -20]
+        car = [sb.make_translator(ch.N, ch.z, o) for o in car_offs]
+        host = np.stack([synth.synth_iq(1234, b * L, L, 0.25, car, [0.3, 0.1], ch.N, ch.fs // 1000).view(np.float32).reshape(L, 2)
+                         for b in range(n_ring)])
+        ring = torch.from_numpy(host).cuda()
+    d_iq = torch.empty(n_ch, 512, 2, dtype=torch.float32, device="cuda")
+    d_au = torch.empty(n_ch, 512, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step(i):
+        if rank == 0:
+            src = ring[i % n_ring]
+        if world > 1:
+            if rank == 0:
+                blk.copy_(src)
+            dist.broadcast(blk, src=0)        # RCCL over xGMI: the shared IQ block
+            p = blk.data_ptr()
+        else:
+            p = src.data_ptr()
+        n = bank.process_device(p, L, d_iq.data_ptr(), d_au.data_ptr(), 512)
+        assert n == 512
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    bank.profile_reset()
+    bank.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    k12_ms, k12_n = bank.profile_read(sb.K_STAGE12)
+    tail_ms, tail_n = bank.profile_read(sb.K_TAIL)
+    agc_ms, agc_n = bank.profile_read(sb.K_AGC)
+    bank.profile_enable(False)
+    assert bool(torch.isfinite(d_au).all()) and bool(torch.isfinite(d_iq).all())
+
+    if rank == 0:
+        total_cs = float(n_ch) * world * L * args.steps
+        value = total_cs / dt / 1e6
+        bpu = algorithmic_bytes_per_channel_sample(ch.m_total)
+        k12_avg_s = k12_ms / max(k12_n, 1) / 1e3
+        achieved = bpu * n_ch * L / k12_avg_s / 1e9 if k12_n else None
+        out = {
+            "metric": "IQ Msamples/s ingested x channels demodulated (channel-samples/s)",
+            "value": value, "unit": "Mch-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{n_ch} channel instances per GPU from one {args.rate} MS/s IQ stream, 8.33 kHz grid "
+                            f"(offsets cycle through all {ch.N} translator steps), 32 ms blocks of {L} complex<float>, "
+                            f"mixer + 4-stage FIR decimation /{ch.m_total} + IF-AGC + AM envelope",
+                "channels_per_gpu": n_ch, "channels_total": n_ch * world, "sample_rate": ch.fs, "block_len": L,
+                "outputs_per_channel_per_block": 512,
+                "parallelism": f"channel-sharded x{world}" + (", RCCL broadcast of the IQ block per step" if world > 1 else ""),
+                "realtime_factor": value * 1e6 / (n_ch * world * ch.fs),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_stage12 (mixer + stages 1-2)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": bpu * n_ch * L,
+                "kernel_ms_avg": {"k_stage12": k12_ms / max(k12_n, 1), "k_tail": tail_ms / max(tail_n, 1),
+                                  "k_agc": agc_ms / max(agc_n, 1)},
+                "launches": int(k12_n),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ch, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    bank.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,30 @@ class BankInfo(C.Structure):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One process, one HIP runtime.
+
+    libsdrxgpu.so needs ``libamdhip64.so.7``.  PyTorch-ROCm wheels bundle their own copy (same
+    SONAME) under ``torch/lib``; if libsdrxgpu pulled in the system copy first and torch were
+    imported later, the process would hold two HIP runtimes and the second one finds no GPU.  So
+    when torch is installed its bundled runtime is loaded first (by path, without importing torch)
+    and libsdrxgpu binds to it by SONAME.  ``SDRXGPU_HIP_RUNTIME=system`` forces /opt/rocm's.
+    """
+    if os.environ.get("SDRXGPU_HIP_RUNTIME", "auto") == "system":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return None
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+    return None
+
+
 def load_library():
     """Load libsdrxgpu.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -65,6 +89,7 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise SdrxGpuError(-2, "libsdrxgpu", f"{LIB_PATH} not built; run __graft_entry__.build() / ./build_lib.sh")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, sz = C.c_void_p, C.c_size_t
     L.sdrxgpu_strerror.restype = C.c_char_p
@@ -97,6 +122,14 @@ EXPORTED_SYMBOLS = [
     "sdrxgpu_bank_profile_read", "sdrxgpu_bank_profile_reset", "sdrxgpu_strerror", "sdrxgpu_last_error",
     "sdrxgpu_version",
 ]
+
+
+class DeviceView:
+    """A raw device address as a float32 array for ``torch.as_tensor(view, device='cuda')`` (zero copy)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": "<f4",
+                                         "data": (int(ptr), False), "version": 2}
 
 
 def _check(rc, what):

@@ -67,7 +67,6 @@ def test_every_time_tiling_gives_the_same_answer(hint):
         c, d = bank.process(x)
         assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
         assert np.array_equal(b.view(np.uint32), d.view(np.uint32))
-        assert rel_err_rows(c, g["iq"][:, : c.shape[1]]) <= RTOL or True
     ref_bank.close()
     bank.close()
 
@@ -225,18 +224,19 @@ def test_device_pointer_entry_and_ingest_buffer():
     assert n == 512
     assert np.array_equal(d_iq.cpu().numpy().reshape(3, 1024).view(np.complex64).view(np.uint32), ref_iq.view(np.uint32))
     assert np.array_equal(d_au.cpu().numpy().view(np.uint32), ref_au.view(np.uint32))
-    # zero-copy: write the block straight into the bank's ingest buffer
+    # zero-copy: write the block straight into the bank's ingest buffer (as an H2D copy or an RCCL
+    # broadcast would), wrapped as a torch tensor through __cuda_array_interface__
     bank.reset()
     ptr, cap = bank.ingest_buffer()
     assert cap >= ch.block_len
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-    assert hip.hipMemcpy(ptr, d_x.data_ptr(), ch.block_len * 8, 3) == 0
+    view = torch.as_tensor(sb.DeviceView(ptr, (ch.block_len, 2)), device="cuda")
+    assert view.data_ptr() == ptr
+    view.copy_(d_x.view(ch.block_len, 2))
     d_iq.zero_()
     torch.cuda.synchronize()
     n = bank.process_device(ptr, ch.block_len, d_iq.data_ptr(), None, 512)
     bank.synchronize()
+    assert n == 512
     assert np.array_equal(d_iq.cpu().numpy().reshape(3, 1024).view(np.complex64).view(np.uint32), ref_iq.view(np.uint32))
     bank.close()
 
