@@ -64,6 +64,34 @@ __device__ __forceinline__ float2 folded_fir(const float2 (&w)[T], const float *
     return acc;
 }
 
+// ---- packed-fp32 forms (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) ----------------------------
+// Measured on MI355X (tools/ubench_valu.hip): a wave64 v_fma_f32 and a wave64 v_pk_fma_f32 both
+// issue in ~4 cycles per SIMD, so the packed forms do twice the work per issue slot.  A complex
+// sample {re, im} is one 64-bit register pair and is processed by ONE packed instruction.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f cmul_pk(v2f x, v2f t)
+{
+    // {xr*tr - xi*ti, xi*tr + xr*ti} in two packed instructions:
+    //   p = {xr, xi} * {tr, tr}                    (pk_mul, t.lo broadcast)
+    //   r = {xi, xr} * {-ti, ti} + p               (pk_fma, x halves swapped, t.hi broadcast, neg_lo)
+    // every shuffle/negation is an op_sel / neg source modifier, not an instruction.
+    const v2f p = x * t.xx;
+    const v2f tn = {-t.y, t.y};
+    return __builtin_elementwise_fma(x.yx, tn, p);
+}
+
+template <int T>
+__device__ __forceinline__ v2f folded_fir_pk(const v2f (&w)[T], const float *__restrict__ h)
+{
+    constexpr int half = (T - 1) / 2;
+    v2f acc = (w[0] + w[T - 1]) * v2f{h[0], h[0]};
+#pragma unroll
+    for (int i = 1; i < half; i++) acc = __builtin_elementwise_fma(w[i] + w[T - 1 - i], v2f{h[i], h[i]}, acc);
+    acc = __builtin_elementwise_fma(w[half], v2f{h[half], h[half]}, acc);
+    return acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_stage12
 // ------------------------------------------------------------------------------------------
@@ -144,18 +172,23 @@ __global__ __launch_bounds__(kWave * W, (W >= 8 ? 4 : (W >= 4 ? 3 : 1))) void k_
 
     int tph = a.tphase0 + p * a.nb * SB;                   // translator index at the first warm-up sample
     tph %= a.N;
+#ifdef SDRX_EXP_SAMETABLE
+    const float2 *__restrict__ tbl = tables;   // timing experiment only: every wave reads channel 0's table
+#else
     const float2 *__restrict__ tbl = tables + (size_t)ch * a.tbl_stride;
+#endif
     const float2 *__restrict__ xsrc = x_in + a.x_base + (size_t)slot0 * SB;   // lane 0, first warm-up sample
 
-    float2 w1c[C1];   // last C1 mixed samples        (stage-1 delay line, newest last)
-    float2 w2c[C2];   // last C2 stage-1 outputs      (stage-2 delay line, newest last)
+    v2f w1c[C1];   // last C1 mixed samples        (stage-1 delay line, newest last)
+    v2f w2c[C2];   // last C2 stage-1 outputs      (stage-2 delay line, newest last)
 #pragma unroll
-    for (int i = 0; i < C1; i++) w1c[i] = make_float2(0.f, 0.f);
+    for (int i = 0; i < C1; i++) w1c[i] = v2f{0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < C2; i++) w2c[i] = make_float2(0.f, 0.f);
+    for (int i = 0; i < C2; i++) w2c[i] = v2f{0.f, 0.f};
 
     const int n_bodies = WU + a.nb;
-    const float4 *__restrict__ xrow = reinterpret_cast<const float4 *>(tile + lane * ROW);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f *__restrict__ xrow = reinterpret_cast<const v4f *>(tile + lane * ROW);
 
     // y2 destination of this lane's first real output
     const int seg = g * kWave + lane;
@@ -176,42 +209,42 @@ __global__ __launch_bounds__(kWave * W, (W >= 8 ? 4 : (W >= 4 ? 3 : 1))) void k_
         }
         __syncthreads();
 
-        const float2 *__restrict__ t = tbl + tph;          // wave-uniform -> scalar loads
+        const v2f *__restrict__ t = reinterpret_cast<const v2f *>(tbl + tph);   // wave-uniform -> scalar loads
         tph += SB;
         if (tph >= a.N) tph -= a.N;
 
-        float2 y2v[Y2B];
+        v2f y2v[Y2B];
 #pragma unroll
         for (int q = 0; q < Y2B; q++) {
             // keep the scheduler from hoisting every LDS/scalar load of the body to its top
-            // (that costs > 256 VGPRs and SGPR spills); one stage-2 output is one scheduling region
+            // (that costs > 256 VGPRs and SGPR spills); one stage-1 output is one scheduling region
             __builtin_amdgcn_sched_barrier(0);
-            float2 win2[T2];
+            v2f win2[T2];
 #pragma unroll
             for (int i = 0; i < C2; i++) win2[i] = w2c[i];
 #pragma unroll
             for (int u = 0; u < M2; u++) {
                 // M1 new mixed samples -> one stage-1 output
                 __builtin_amdgcn_sched_barrier(0);
-                float2 win[T1];
+                v2f win[T1];
 #pragma unroll
                 for (int i = 0; i < C1; i++) win[i] = w1c[i];
 #pragma unroll
                 for (int e = 0; e < M1; e++) {
                     const int idx = (q * M2 + u) * M1 + e;
-                    const float4 xx = xrow[idx >> 1];
-                    const float2 xv = (idx & 1) ? make_float2(xx.z, xx.w) : make_float2(xx.x, xx.y);
-                    win[C1 + e] = cmul(xv, t[idx]);
+                    const v4f xx = xrow[idx >> 1];
+                    const v2f xv = (idx & 1) ? xx.zw : xx.xy;
+                    win[C1 + e] = cmul_pk(xv, t[idx]);
                 }
-                win2[C2 + u] = folded_fir<T1>(win, taps.h1);
+                win2[C2 + u] = folded_fir_pk<T1>(win, taps.h1);
                 // pin the stage-1 output here: without it LLVM sinks the arithmetic down to the
                 // stage-2 FIR and every LDS read of the body stays live (spills)
-                asm volatile("" : "+v"(win2[C2 + u].x), "+v"(win2[C2 + u].y));
+                asm volatile("" : "+v"(win2[C2 + u]));
 #pragma unroll
                 for (int i = 0; i < C1; i++) w1c[i] = win[i + M1];
             }
-            y2v[q] = folded_fir<T2>(win2, taps.h2);
-            asm volatile("" : "+v"(y2v[q].x), "+v"(y2v[q].y));
+            y2v[q] = folded_fir_pk<T2>(win2, taps.h2);
+            asm volatile("" : "+v"(y2v[q]));
 #pragma unroll
             for (int i = 0; i < C2; i++) w2c[i] = win2[i + M2];
         }
@@ -220,7 +253,7 @@ __global__ __launch_bounds__(kWave * W, (W >= 8 ? 4 : (W >= 4 ? 3 : 1))) void k_
             if (ch_ok) {
 #pragma unroll
                 for (int q = 0; q < Y2B; q++)
-                    if (jrel + q < a.n_y2_new) ydst[jrel + q] = y2v[q];
+                    if (jrel + q < a.n_y2_new) ydst[jrel + q] = make_float2(y2v[q].x, y2v[q].y);
             }
             jrel += Y2B;
         }
@@ -228,38 +261,43 @@ __global__ __launch_bounds__(kWave * W, (W >= 8 ? 4 : (W >= 4 ? 3 : 1))) void k_
 }
 
 // ------------------------------------------------------------------------------------------
-// k_tail: the remaining one or two decimator stages; one workgroup per channel.
+// k_tail: the remaining one or two decimator stages.  One workgroup per (channel, tile of
+// tile_b final outputs); the stage-2 outputs a tile needs (its own span plus the FIR history in
+// front of it) are staged in LDS, stage A is computed into LDS, stage B from there.  Tiles are
+// small (tens of KB of LDS) so that several workgroups per CU overlap their HBM reads with each
+// other's arithmetic: this kernel is bound by streaming the stage-2 scratch (8 B per 25 input
+// samples per channel).
+//
+// The stage-2 history a channel carries from call to call lives in a separate ping-pong buffer
+// (hist_in -> hist_out) so that no tile reads what another tile of the same launch writes.
+// Row coordinates below: index p of the virtual row [hist (H entries) | new (n_y2_new entries)].
 // ------------------------------------------------------------------------------------------
 struct TailArgs {
-    float2 *y2;             // [n_ch][y2_stride]: [0,hist) history, [hist, hist+n_new) new
-    float2 *iq_out;         // [n_ch][out_stride] or nullptr
-    float2 *iq_keep;        // [n_ch][keep_stride] compact copy for k_agc (never null)
+    const float2 *y2_new;   // [n_ch][y2_stride]
+    const float2 *hist_in;  // [n_ch][hist]
+    float2       *hist_out; // [n_ch][hist]
+    float2       *iq_out;   // [n_ch][out_stride] or nullptr
+    float2       *iq_keep;  // [n_ch][keep_stride] compact copy for k_agc (never null)
     int n_ch;
-    int y2_stride, y2_hist, n_y2_new;
+    int y2_stride, hist, n_y2_new;
     int out_stride, keep_stride;
     int has_a;              // 1: stage A then stage B; 0: stage B only
     int mA, tA, mB, tB;
-    int n_a;                // stage-A outputs to compute
-    int pA0;                // y2 index (in the [hist|new] row) of the first A window's oldest sample
+    int pA0;                // row index of the oldest sample of stage-A output 0's window
+    int pB0;                // index (in stage-A outputs, or in the row if !has_a) of the oldest sample of output 0's window
     int n_b;                // stage-B outputs = outputs of the call
-    int pB0;                // index of the first B window's oldest sample (in A outputs, or in y2 if !has_a)
+    int tile_b;             // outputs per tile
+    int n_tiles;            // >= 1
     float hA[kMaxHalfTaps];
     float hB[kMaxHalfTaps];
 };
 
-__device__ __forceinline__ float2 folded_fir_lds(const float2 *__restrict__ w, int T, const float *__restrict__ h)
+__device__ __forceinline__ v2f folded_fir_lds(const v2f *__restrict__ w, int T, const float *__restrict__ h)
 {
     const int half = (T - 1) >> 1;
-    float2 acc = make_float2(0.f, 0.f);
-    for (int i = 0; i < half; i++) {
-        const float2 lo = w[i], hi = w[T - 1 - i];
-        acc.x = fmaf(lo.x + hi.x, h[i], acc.x);
-        acc.y = fmaf(lo.y + hi.y, h[i], acc.y);
-    }
-    const float2 c = w[half];
-    acc.x = fmaf(c.x, h[half], acc.x);
-    acc.y = fmaf(c.y, h[half], acc.y);
-    return acc;
+    v2f acc = {0.f, 0.f};
+    for (int i = 0; i < half; i++) acc = __builtin_elementwise_fma(w[i] + w[T - 1 - i], v2f{h[i], h[i]}, acc);
+    return __builtin_elementwise_fma(w[half], v2f{h[half], h[half]}, acc);
 }
 
 __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
@@ -267,106 +305,148 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     __shared__ float hA[kMaxHalfTaps], hB[kMaxHalfTaps];
 
-    const int ch = blockIdx.x;
+    const int ch = blockIdx.x / a.n_tiles;
+    const int q = blockIdx.x - ch * a.n_tiles;
     const int tid = threadIdx.x;
-    const int n2 = a.y2_hist + a.n_y2_new;
-    float2 *__restrict__ row = a.y2 + (size_t)ch * a.y2_stride;
-    float2 *s2 = smem;                 // [n2]
-    float2 *s3 = smem + n2;            // [n_a]
+    const float2 *__restrict__ ynew = a.y2_new + (size_t)ch * a.y2_stride;
+    const float2 *__restrict__ hin = a.hist_in + (size_t)ch * a.hist;
 
     if (tid < kMaxHalfTaps) {
         hA[tid] = a.hA[tid];
         hB[tid] = a.hB[tid];
     }
-    for (int i = tid; i < n2; i += blockDim.x) s2[i] = row[i];
+
+    // history for the next call = the last `hist` entries of the row [hist | new]
+    if (q == a.n_tiles - 1) {
+        float2 *__restrict__ hout = a.hist_out + (size_t)ch * a.hist;
+        for (int i = tid; i < a.hist; i += blockDim.x) {
+            const int idx = a.n_y2_new + i;
+            hout[i] = idx < a.hist ? hin[idx] : ynew[idx - a.hist];
+        }
+    }
+
+    const int s0 = q * a.tile_b;
+    const int nbt = min(a.n_b - s0, a.tile_b);             // outputs of this tile
+    if (nbt <= 0) return;
+
+    // spans (all in units of samples of the respective rate)
+    int r0 = 0, nr = 0, p0, np;
+    if (a.has_a) {
+        r0 = a.pB0 + a.mB * s0;                            // first stage-A output needed
+        nr = a.mB * (nbt - 1) + a.tB;
+        p0 = a.pA0 + a.mA * r0;
+        np = a.mA * (nr - 1) + a.tA;
+    } else {
+        p0 = a.pB0 + a.mB * s0;
+        np = a.mB * (nbt - 1) + a.tB;
+    }
+    v2f *s2 = reinterpret_cast<v2f *>(smem);               // [np]
+    v2f *s3 = s2 + np;                                     // [nr]
+
+    for (int i = tid; i < np; i += blockDim.x) {
+        const int p = p0 + i;
+        const float2 v = p < a.hist ? hin[p] : ynew[p - a.hist];
+        s2[i] = v2f{v.x, v.y};
+    }
     __syncthreads();
 
-    // history for the next call: the last y2_hist stage-2 outputs, time order kept
-    for (int i = tid; i < a.y2_hist; i += blockDim.x) row[i] = s2[a.n_y2_new + i];
-
-    const float2 *bsrc = s2;
+    const v2f *bsrc = s2;
     if (a.has_a) {
-        for (int r = tid; r < a.n_a; r += blockDim.x)
-            s3[r] = folded_fir_lds(s2 + a.pA0 + a.mA * r, a.tA, hA);
+        for (int r = tid; r < nr; r += blockDim.x) s3[r] = folded_fir_lds(s2 + a.mA * r, a.tA, hA);
         __syncthreads();
         bsrc = s3;
     }
-    for (int s = tid; s < a.n_b; s += blockDim.x) {
-        const float2 y = folded_fir_lds(bsrc + a.pB0 + a.mB * s, a.tB, hB);
-        if (a.iq_out) a.iq_out[(size_t)ch * a.out_stride + s] = y;
-        a.iq_keep[(size_t)ch * a.keep_stride + s] = y;
+    for (int s = tid; s < nbt; s += blockDim.x) {
+        const v2f y = folded_fir_lds(bsrc + a.mB * s, a.tB, hB);
+        const float2 o = make_float2(y.x, y.y);
+        if (a.iq_out) a.iq_out[(size_t)ch * a.out_stride + s0 + s] = o;
+        a.iq_keep[(size_t)ch * a.keep_stride + s0 + s] = o;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_agc: lane = channel, strictly serial over the block's outputs (the only true recurrence
-// of the path).  64 channels per single-wave workgroup; the [ch][n] rows are transposed
-// through LDS in tiles of 64 outputs so that global traffic stays row-contiguous.
+// of the path: 512 dependent steps per channel per block).  Each lane streams its own row
+// (16-byte loads, 8 samples ahead), so no transposition is needed; 64 channels per wave.
 // ------------------------------------------------------------------------------------------
 struct AgcParams {
     float attack, decay, reference, min_gain, max_gain, alpha;
 };
 
 struct AgcArgs {
-    const float2 *iq;        // [n_ch][iq_stride] decimated IQ
+    const float2 *iq;        // [n_ch][iq_stride] decimated IQ; rows 16-byte aligned
     float        *audio;     // [n_ch][out_stride]
     float4       *state;     // [n_ch] {agc.gain, agc.power, lf.gain, lf.power}
     int n_ch, n_out, iq_stride, out_stride;
     int lf_active;
+    int audio_vec;           // 1: audio rows are 16-byte aligned (vector stores)
     AgcParams agc, lf;
 };
 
+struct AgcState {
+    float g, pw, gl, pl;
+};
+
+__device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const AgcParams &A, const AgcParams &Lf, int lf_active)
+{
+    // AGC::adjust, agc.hpp:48-69 (same operation order, unfused)
+    const float yr = __fmul_rn(x.x, st.g), yi = __fmul_rn(x.y, st.g);
+    const float nrm = __fadd_rn(__fmul_rn(yr, yr), __fmul_rn(yi, yi));
+    st.pw = __fadd_rn(st.pw, __fmul_rn(A.alpha, __fsub_rn(nrm, st.pw)));
+    const float err = __fsub_rn(A.reference, st.pw);
+    st.g = __fadd_rn(st.g, __fmul_rn(err > 0.0f ? A.decay : A.attack, err));
+    st.g = st.g < A.min_gain ? A.min_gain : (st.g > A.max_gain ? A.max_gain : st.g);
+    // Demod::demod AM: std::abs, sdrx.cpp:178-180
+    const float s = __fsqrt_rn(nrm);
+    // LfAGC::adjust, agc.hpp:106-131
+    const float sl = __fmul_rn(s, st.gl);
+    st.pl = __fadd_rn(st.pl, __fmul_rn(Lf.alpha, __fsub_rn(__fmul_rn(sl, sl), st.pl)));
+    const float errl = __fsub_rn(Lf.reference, __fsqrt_rn(st.pl));
+    st.gl = __fadd_rn(st.gl, __fmul_rn(errl > 0.0f ? Lf.decay : Lf.attack, errl));
+    st.gl = st.gl < Lf.min_gain ? Lf.min_gain : (st.gl > Lf.max_gain ? Lf.max_gain : st.gl);
+    return lf_active ? sl : s;
+}
+
 __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
 {
-    constexpr int TS = 64;                    // outputs per tile
-    __shared__ float2 tin[kWave * (TS + 1)];
-    __shared__ float tout[kWave * (TS + 1)];
+    const int ch = blockIdx.x * kWave + threadIdx.x;
+    if (ch >= a.n_ch) return;
+    const float2 *__restrict__ row = a.iq + (size_t)ch * a.iq_stride;
+    float *__restrict__ out = a.audio + (size_t)ch * a.out_stride;
+    const float4 s4 = a.state[ch];
+    AgcState st = {s4.x, s4.y, s4.z, s4.w};
 
-    const int lane = threadIdx.x;
-    const int ch0 = blockIdx.x * kWave;
-    const int ch = ch0 + lane;
-    const bool ok = ch < a.n_ch;
-
-    float4 st = ok ? a.state[ch] : make_float4(1.f, 0.f, 1.f, 0.f);
-    float g = st.x, pw = st.y, gl = st.z, pl = st.w;
-
-    for (int base = 0; base < a.n_out; base += TS) {
-        const int cnt = min(TS, a.n_out - base);
-        // rows in: lane = sample within the tile
-        for (int r = 0; r < kWave; r++) {
-            const int c = ch0 + r;
-            if (c < a.n_ch && lane < cnt) tin[r * (TS + 1) + lane] = a.iq[(size_t)c * a.iq_stride + base + lane];
-        }
-        __syncthreads();
-        if (ok) {
-            for (int i = 0; i < cnt; i++) {
-                const float2 x = tin[lane * (TS + 1) + i];
-                // AGC::adjust, agc.hpp:48-69 (same operation order, unfused)
-                const float yr = x.x * g, yi = x.y * g;
-                const float nrm = __fadd_rn(__fmul_rn(yr, yr), __fmul_rn(yi, yi));
-                pw = __fadd_rn(pw, __fmul_rn(a.agc.alpha, __fsub_rn(nrm, pw)));
-                const float err = __fsub_rn(a.agc.reference, pw);
-                g = __fadd_rn(g, __fmul_rn(err > 0.0f ? a.agc.decay : a.agc.attack, err));
-                g = g < a.agc.min_gain ? a.agc.min_gain : (g > a.agc.max_gain ? a.agc.max_gain : g);
-                // Demod::demod AM: std::abs, sdrx.cpp:178-180
-                const float s = __fsqrt_rn(__fadd_rn(__fmul_rn(yr, yr), __fmul_rn(yi, yi)));
-                // LfAGC::adjust, agc.hpp:106-131
-                const float sl = __fmul_rn(s, gl);
-                pl = __fadd_rn(pl, __fmul_rn(a.lf.alpha, __fsub_rn(__fmul_rn(sl, sl), pl)));
-                const float errl = __fsub_rn(a.lf.reference, __fsqrt_rn(pl));
-                gl = __fadd_rn(gl, __fmul_rn(errl > 0.0f ? a.lf.decay : a.lf.attack, errl));
-                gl = gl < a.lf.min_gain ? a.lf.min_gain : (gl > a.lf.max_gain ? a.lf.max_gain : gl);
-                tout[lane * (TS + 1) + i] = a.lf_active ? sl : s;
-            }
-        }
-        __syncthreads();
-        for (int r = 0; r < kWave; r++) {
-            const int c = ch0 + r;
-            if (c < a.n_ch && lane < cnt) a.audio[(size_t)c * a.out_stride + base + lane] = tout[r * (TS + 1) + lane];
-        }
-        __syncthreads();
+    const int n8 = a.n_out & ~7;
+    const float4 *__restrict__ row4 = reinterpret_cast<const float4 *>(row);
+    float4 nx[4];
+    if (n8 > 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) nx[k] = row4[k];
     }
-    if (ok) a.state[ch] = make_float4(g, pw, gl, pl);
+    for (int base = 0; base < n8; base += 8) {
+        float4 cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) cur[k] = nx[k];
+        if (base + 8 < n8) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) nx[k] = row4[(base + 8) / 2 + k];
+        }
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            y[2 * k + 0] = agc_step(make_float2(cur[k].x, cur[k].y), st, a.agc, a.lf, a.lf_active);
+            y[2 * k + 1] = agc_step(make_float2(cur[k].z, cur[k].w), st, a.agc, a.lf, a.lf_active);
+        }
+        if (a.audio_vec) {
+            reinterpret_cast<float4 *>(out + base)[0] = make_float4(y[0], y[1], y[2], y[3]);
+            reinterpret_cast<float4 *>(out + base)[1] = make_float4(y[4], y[5], y[6], y[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) out[base + k] = y[k];
+        }
+    }
+    for (int i = n8; i < a.n_out; i++) out[i] = agc_step(row[i], st, a.agc, a.lf, a.lf_active);
+    a.state[ch] = make_float4(st.g, st.pw, st.gl, st.pl);
 }
 
 // copy the last `hist` samples of [0, hist + n_new) to the front (ranges may overlap)

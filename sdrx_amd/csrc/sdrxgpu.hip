@@ -179,6 +179,10 @@ struct sdrxgpu_bank {
 
     // device memory
     float2 *d_x = nullptr, *d_tables = nullptr, *d_y2 = nullptr, *d_keep = nullptr;
+    float2 *d_hist[2] = {nullptr, nullptr};   // stage-2 history, ping-pong between calls
+    int hist_cur = 0;
+    int tile_b = 128;                         // final outputs per k_tail workgroup
+    size_t tail_lds = 0;
     float *d_audio_keep = nullptr;
     float4 *d_state = nullptr;
     size_t device_bytes = 0;
@@ -214,6 +218,8 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_x);
     (void)hipFree(b->d_tables);
     (void)hipFree(b->d_y2);
+    (void)hipFree(b->d_hist[0]);
+    (void)hipFree(b->d_hist[1]);
     (void)hipFree(b->d_keep);
     (void)hipFree(b->d_audio_keep);
     (void)hipFree(b->d_state);
@@ -225,6 +231,9 @@ static int init_state(sdrxgpu_bank *b)
 {
     HIPCHK(hipMemsetAsync(b->d_x, 0, b->x_capacity * sizeof(float2), b->stream));
     HIPCHK(hipMemsetAsync(b->d_y2, 0, (size_t)b->n_ch * b->y2_stride * sizeof(float2), b->stream));
+    HIPCHK(hipMemsetAsync(b->d_hist[0], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
+    HIPCHK(hipMemsetAsync(b->d_hist[1], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
+    b->hist_cur = 0;
     std::vector<float4> st(b->n_ch, make_float4(b->agc.init_gain, b->agc.init_power, b->lf.init_gain, b->lf.init_power));
     HIPCHK(hipMemcpyAsync(b->d_state, st.data(), st.size() * sizeof(float4), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -317,17 +326,23 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
 
     b->max_chunk = cfg->max_in_len ? cfg->max_in_len : 512u * b->m_total;   // 32 ms block of this chain
     const int max_y2 = (int)(b->max_chunk / b->MM) + 1;
-    b->y2_stride = ((b->y2_hist + max_y2 + 63) / 64) * 64;
-    b->keep_stride = (int)(b->max_chunk / b->m_total) + 1;
+    b->y2_stride = ((max_y2 + 63) / 64) * 64;
+    b->keep_stride = (((int)(b->max_chunk / b->m_total) + 1 + 3) / 4) * 4;   // rows stay 16-byte aligned
 
-    // LDS budget of k_tail: [hist + new] stage-2 outputs + stage-A outputs
+    // LDS of one k_tail tile: the stage-2 span of tile_b outputs (+ FIR history) and its stage-A outputs
     {
-        size_t n_a = (cfg->n_stages == 4) ? (size_t)(b->y2_hist + max_y2) / b->m[2] + 2 : 0;
-        size_t lds = ((size_t)b->y2_hist + max_y2 + n_a) * sizeof(float2);
-        if (lds > 150 * 1024) {
+        const int tB = (int)b->ntaps[cfg->n_stages - 1], mB = (int)b->m[cfg->n_stages - 1];
+        size_t np, nr = 0;
+        if (cfg->n_stages == 4) {
+            nr = (size_t)mB * (b->tile_b - 1) + tB;
+            np = (size_t)b->m[2] * (nr - 1) + b->ntaps[2];
+        } else {
+            np = (size_t)mB * (b->tile_b - 1) + tB;
+        }
+        b->tail_lds = (np + nr) * sizeof(float2);
+        if (b->tail_lds > 150 * 1024) {
             free_bank(b);
-            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: max_in_len %u needs %zu B of LDS in the tail kernel (max 153600); "
-                        "use a smaller max_in_len (longer calls are split internally)", b->max_chunk, lds);
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tail stages need %zu B of LDS per tile (max 153600)", b->tail_lds);
         }
     }
 
@@ -377,6 +392,8 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     if ((rc = dev_alloc(b, (void **)&b->d_x, b->x_capacity * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_tables, (size_t)b->n_ch * b->tbl_stride * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_y2, (size_t)b->n_ch * b->y2_stride * sizeof(float2))) ||
+        (rc = dev_alloc(b, (void **)&b->d_hist[0], (size_t)b->n_ch * b->y2_hist * sizeof(float2))) ||
+        (rc = dev_alloc(b, (void **)&b->d_hist[1], (size_t)b->n_ch * b->y2_hist * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_keep, (size_t)b->n_ch * b->keep_stride * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_audio_keep, (size_t)b->n_ch * b->keep_stride * sizeof(float))) ||
         (rc = dev_alloc(b, (void **)&b->d_state, (size_t)b->n_ch * sizeof(float4)))) {
@@ -587,7 +604,7 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         a.N = b->Neff;
         a.spacing = b->spacing;
         a.y2_stride = b->y2_stride;
-        a.y2_hist = b->y2_hist;
+        a.y2_hist = 0;                                                 // new outputs start at row index 0
         a.n_y2_new = n_y2_new;
         a.x_base = (int)(first - (n0 - b->HIST));                      // d_x[0] holds abs sample n0 - HIST
         a.tphase0 = (int)(((first % b->Neff) + b->Neff) % b->Neff);    // trans_pos_ of that sample (msd.hpp:135)
@@ -613,10 +630,12 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         TailArgs t;
         memset(&t, 0, sizeof(t));
         const int ns = (int)b->n_stages;
-        t.y2 = b->d_y2;
+        t.y2_new = b->d_y2;
+        t.hist_in = b->d_hist[b->hist_cur];
+        t.hist_out = b->d_hist[b->hist_cur ^ 1];
         t.n_ch = (int)b->n_ch;
         t.y2_stride = b->y2_stride;
-        t.y2_hist = b->y2_hist;
+        t.hist = b->y2_hist;
         t.n_y2_new = n_y2_new;
         t.keep_stride = b->keep_stride;
         t.iq_keep = b->d_keep;
@@ -625,20 +644,17 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         t.tB = (int)b->ntaps[ns - 1];
         for (int i = 0; i < (t.tB + 1) / 2; i++) t.hB[i] = b->taps[ns - 1][i];
         long long q_prev, q1;
-        const long long y2_first = j0 - b->y2_hist;                    // abs stage-2 index held at row[0]
+        const long long y2_first = j0 - b->y2_hist;                    // abs stage-2 index of row entry 0
         if (t.has_a) {
             t.mA = (int)b->m[2];
             t.tA = (int)b->ntaps[2];
             for (int i = 0; i < (t.tA + 1) / 2; i++) t.hA[i] = b->taps[2][i];
-            const long long iA_hi = j1 / t.mA;
             q_prev = (j0 / t.mA) / t.mB;
-            q1 = iA_hi / t.mB;
+            q1 = (j1 / t.mA) / t.mB;
             const long long i_lo = (long long)t.mB * (q_prev + 1) - t.tB;       // oldest stage-A output needed
-            t.n_a = (int)std::max(0LL, iA_hi - i_lo);
             t.pA0 = (int)((long long)t.mA * i_lo + t.mA - t.tA - y2_first);
             t.pB0 = 0;
-            if (q1 == q_prev) t.n_a = 0;
-            if (t.n_a > 0 && t.pA0 < 0) return fail(SDRXGPU_ERR_HIP, "internal: pA0 %d < 0", t.pA0);
+            if (q1 > q_prev && t.pA0 < 0) return fail(SDRXGPU_ERR_HIP, "internal: pA0 %d < 0", t.pA0);
         } else {
             q_prev = j0 / t.mB;
             q1 = j1 / t.mB;
@@ -646,16 +662,19 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
             if (q1 > q_prev && t.pB0 < 0) return fail(SDRXGPU_ERR_HIP, "internal: pB0 %d < 0", t.pB0);
         }
         t.n_b = (int)(q1 - q_prev);
+        t.tile_b = b->tile_b;
+        t.n_tiles = std::max(1, (t.n_b + b->tile_b - 1) / b->tile_b);
         if (out_off + (size_t)t.n_b > out_stride && (d_iq_out || d_audio_out))
             return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride);
+        if (t.n_b > b->keep_stride) return fail(SDRXGPU_ERR_HIP, "internal: %d outputs > keep_stride %d", t.n_b, b->keep_stride);
         t.iq_out = d_iq_out ? d_iq_out + out_off : nullptr;
         t.out_stride = (int)out_stride;
-        const size_t lds = ((size_t)b->y2_hist + n_y2_new + t.n_a) * sizeof(float2);
         {
             ProfScope ps(b, SDRXGPU_K_TAIL);
-            hipLaunchKernelGGL(k_tail, dim3(b->n_ch), dim3(256), lds, b->stream, t);
+            hipLaunchKernelGGL(k_tail, dim3(b->n_ch * t.n_tiles), dim3(256), b->tail_lds, b->stream, t);
             HIPCHK(hipGetLastError());
         }
+        b->hist_cur ^= 1;
 
         // ---- AGC -> |.| -> LF AGC ----
         if (t.n_b > 0) {
@@ -668,6 +687,7 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
             g.n_ch = (int)b->n_ch;
             g.n_out = t.n_b;
             g.lf_active = (b->flags & SDRXGPU_FLAG_LF_AGC_ACTIVE) ? 1 : 0;
+            g.audio_vec = (((uintptr_t)g.audio & 15) == 0 && (g.out_stride & 3) == 0) ? 1 : 0;
             auto fill = [](AgcParams &p, const sdrxgpu_agc_params &s) {
                 p.attack = s.attack;
                 p.decay = s.decay;
