@@ -75,10 +75,19 @@ __device__ __forceinline__ v2f cmul_pk(v2f x, v2f t)
     // {xr*tr - xi*ti, xi*tr + xr*ti} in two packed instructions:
     //   p = {xr, xi} * {tr, tr}                    (pk_mul, t.lo broadcast)
     //   r = {xi, xr} * {-ti, ti} + p               (pk_fma, x halves swapped, t.hi broadcast, neg_lo)
-    // every shuffle/negation is an op_sel / neg source modifier, not an instruction.
-    const v2f p = x * t.xx;
-    const v2f tn = {-t.y, t.y};
-    return __builtin_elementwise_fma(x.yx, tn, p);
+    // Every shuffle/negation is an op_sel / neg source modifier.  Written as inline asm because
+    // hipcc (ROCm 7.2) materialises {-ti, ti} with a v_xor + v_mov per sample instead of neg_lo when
+    // t lives in VGPRs (+30 % VALU instructions in this kernel).  The s_nop 0 after each packed op is
+    // the wait state gfx950 needs before a VALU instruction may read a packed op's result (hipcc
+    // inserts the same nop in its own code; it does not look inside asm).
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "s_nop 0"
+        : "=&v"(r)
+        : "v"(x), "v"(t));
+    return r;
 }
 
 template <int T>
@@ -101,10 +110,9 @@ struct Stage12Taps {
     float h2[(T2 + 1) / 2];
 };
 
-// The three pointers are separate __restrict__ kernel parameters (not struct members) so that
-// the compiler may prove the translator table is never written by this kernel and fetch it
-// through the scalar cache (s_load):
-//   x      input ring: [history | new block | slack]
+// Pointer parameters of k_stage12 (separate __restrict__ kernel parameters):
+//   x      input ring: [history | new block | slack]; the first sample of every tile row is at an
+//          even index (16-byte aligned source for the 16-byte LDS-DMA)
 //   tables [n_ch][tbl_stride] translator tables, wrapped by SB entries
 //   y2     [n_ch][y2_stride]; new stage-2 outputs go to y2_hist + j
 struct Stage12Args {
@@ -115,49 +123,78 @@ struct Stage12Args {
     int y2_stride;
     int y2_hist;
     int n_y2_new;           // stage-2 outputs this launch must produce (per channel)
-    int x_base;             // x index of the first warm-up sample of lane 0 of time-wave 0
-    int tphase0;            // translator index of that sample
+    int x_base;             // x index of the first warm-up sample of lane 0 of time-wave 0 (even)
+    int tphase0;            // translator-table index of that sample (even; see the host's odd-phase copy)
     int nb;                 // bodies per lane (divides spacing/SB)
     int P;                  // (spacing/SB)/nb sub-phases per segment
     int n_wt;               // time-waves = G*P
     int n_chgroups;
+    int n_cgx;              // n_chgroups rounded up to a multiple of 8 (XCD-aware block map)
 };
 
-// Row stride of the LDS input tile in float2 units: SB samples + pad.  With SB*8 a multiple of
-// 16 bytes, pad = 2 keeps rows 16-byte aligned for ds_read_b128; the resulting dword stride
-// (2*SB+4) makes the 16-lane groups of a b128 read hit 16 distinct 4-bank slots (checked on the
-// host for each instantiation, see lds_row_conflict_free()).
-template <int SB>
+// LDS tile geometry.  One buffer = 64 input rows (one per lane / time segment) + W translator rows
+// (one per wave / channel), every row SB samples (8 B each) + 16 B pad.  The pad keeps rows 16-byte
+// aligned and makes the row pitch (2*SB+4 dwords) fall on distinct 4-bank slots within each 16-lane
+// group of a ds_read_b128 (conflict-free row-per-lane reads; translator rows are read as broadcasts).
+template <int SB, int W>
 struct TileGeom {
-    static constexpr int row_f2 = SB + 2;
-    static constexpr int bytes = kWave * row_f2 * 8;
+    static constexpr int row_bytes = SB * 8 + 16;
+    static constexpr int rows = kWave + W;
+    static constexpr int buf_bytes = rows * row_bytes;
+    static constexpr int lanes_per_row = SB / 2;            // 16-byte DMA pieces per row
 };
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// One row of SB samples, global -> LDS, without touching VGPRs (global_load_lds_dwordx4):
+// lane i (< SB/2) moves 16 bytes from src + 2*i samples to dst + 16*i.
+template <int SB>
+__device__ __forceinline__ void dma_row(const float2 *src_row /* wave-uniform */, char *lds_row /* wave-uniform */, int lane)
+{
+    static_assert(SB / 2 <= kWave, "row longer than one DMA instruction (64 x 16 B)");
+    if (lane < SB / 2) {
+        // uniform 64-bit base + 32-bit per-lane byte offset -> the saddr + voffset form of the
+        // instruction (no 64-bit per-lane address registers).  generic -> global / LDS address spaces:
+        // a global generic pointer is its own global address; the low 32 bits of a generic LDS pointer
+        // are the LDS offset.
+        const char *g = reinterpret_cast<const char *>(src_row) + (uint32_t)(lane * 16);
+        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)g, (lds_void *)(uint32_t)(uintptr_t)lds_row, 16, 0, 0);
+    }
+}
 
 template <int M1, int T1, int M2, int T2, int Y2B, int W>
-__global__ __launch_bounds__(kWave * W, (W >= 8 ? 4 : (W >= 4 ? 3 : 1))) void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ tables,
-                                                             float2 *__restrict__ y2_out, const Stage12Args a,
-                                                             const Stage12Taps<T1, T2> taps)
+__global__ __launch_bounds__(kWave * W, (W >= 16 ? 4 : (W >= 8 ? 2 : 1)))
+void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
+               const Stage12Args a, const Stage12Taps<T1, T2> taps)
 {
     constexpr int SB = M1 * M2 * Y2B;                      // input samples per body
     constexpr int NY1 = M2 * Y2B;                          // stage-1 outputs per body
     constexpr int HALO = M1 * (T2 - M2) + (T1 - M1);       // input history a lane needs
     constexpr int WU = (HALO + SB - 1) / SB;               // warm-up bodies
-    constexpr int ROW = TileGeom<SB>::row_f2;
     constexpr int C1 = T1 - M1;                            // carried mixed samples
     constexpr int C2 = T2 - M2;                            // carried stage-1 outputs
-    static_assert(SB % 2 == 0, "body must hold an even number of samples (16-byte LDS reads)");
+    using G = TileGeom<SB, W>;
+    constexpr int RPW = kWave / W;                         // input rows each wave fetches per body
+    static_assert(SB % 2 == 0, "body must hold an even number of samples (16-byte LDS accesses)");
     static_assert(SB >= C1 && NY1 >= C2, "a body must refresh both delay lines completely");
+    static_assert(kWave % W == 0, "W must divide 64");
 
-    __shared__ __attribute__((aligned(16))) float2 tile[kWave * ROW];
+    __shared__ __attribute__((aligned(16))) char lds[2 * G::buf_bytes];
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // blockIdx -> (channel group, time-wave).  Consecutive blocks walk the time-waves of one
-    // channel group first, so the blocks that share a translator table are dispatched together.
-    const int wt = blockIdx.x % a.n_wt;
-    const int cg = blockIdx.x / a.n_wt;
+    // blockIdx -> (channel group, time-wave).  Blocks are dealt round-robin over the 8 XCDs
+    // (b % 8 labels the XCD group), so the time-waves of one channel group -- which read the same
+    // translator tables -- are given the same b % 8 and consecutive b / 8: they meet in one XCD's L2.
+    const int xcd = blockIdx.x & 7;
+    const int qq = blockIdx.x >> 3;
+    const int wt = qq % a.n_wt;
+    const int cg = (qq / a.n_wt) * 8 + xcd;
+    if (cg >= a.n_chgroups) return;
     const int g = wt / a.P;
     const int p = wt - g * a.P;
     const int bps = a.nb * a.P;                            // bodies per segment = spacing / SB
@@ -173,11 +210,25 @@ __global__ __launch_bounds__(kWave * W, (W >= 8 ? 4 : (W >= 4 ? 3 : 1))) void k_
     int tph = a.tphase0 + p * a.nb * SB;                   // translator index at the first warm-up sample
     tph %= a.N;
 #ifdef SDRX_EXP_SAMETABLE
-    const float2 *__restrict__ tbl = tables;   // timing experiment only: every wave reads channel 0's table
+    const float2 *tbl = tables;   // timing experiment only: every wave reads channel 0's table
 #else
-    const float2 *__restrict__ tbl = tables + (size_t)ch * a.tbl_stride;
+    const float2 *tbl = tables + (size_t)ch * a.tbl_stride;
 #endif
-    const float2 *__restrict__ xsrc = x_in + a.x_base + (size_t)slot0 * SB;   // lane 0, first warm-up sample
+    const float2 *xsrc = x_in + a.x_base + (size_t)slot0 * SB;   // lane 0, first warm-up sample
+
+    const int n_bodies = WU + a.nb;
+
+    // issue the DMA of body `b` into LDS buffer `bi`: this wave's share of the 64 input rows + its
+    // own channel's translator row
+    auto issue_body = [&](int b, int bi, int tphb) {
+        char *buf = lds + bi * G::buf_bytes;
+#pragma unroll
+        for (int rr = 0; rr < RPW; rr++) {
+            const int r = wave * RPW + rr;
+            dma_row<SB>(xsrc + (size_t)b * SB + (size_t)r * a.spacing, buf + r * G::row_bytes, lane);
+        }
+        dma_row<SB>(tbl + tphb, buf + (kWave + wave) * G::row_bytes, lane);
+    };
 
     v2f w1c[C1];   // last C1 mixed samples        (stage-1 delay line, newest last)
     v2f w2c[C2];   // last C2 stage-1 outputs      (stage-2 delay line, newest last)
@@ -186,56 +237,78 @@ __global__ __launch_bounds__(kWave * W, (W >= 8 ? 4 : (W >= 4 ? 3 : 1))) void k_
 #pragma unroll
     for (int i = 0; i < C2; i++) w2c[i] = v2f{0.f, 0.f};
 
-    const int n_bodies = WU + a.nb;
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f *__restrict__ xrow = reinterpret_cast<const v4f *>(tile + lane * ROW);
-
     // y2 destination of this lane's first real output
     const int seg = g * kWave + lane;
     int jrel = (seg * bps + a.nb * p) * Y2B;
     float2 *__restrict__ ydst = y2_out + (size_t)ch * a.y2_stride + a.y2_hist;
 
-    for (int b = 0; b < n_bodies; b++) {
-        // ---- stage the 64 x SB input tile: row r = lane r's next SB samples -----------------
-        __syncthreads();
-        {
-            const float2 *__restrict__ src = xsrc + (size_t)b * SB;
-#pragma unroll 4
-            for (int e = tid; e < kWave * SB; e += kWave * W) {
-                const int r = e / SB;
-                const int c = e - r * SB;
-                tile[r * ROW + c] = src[(size_t)r * a.spacing + c];
-            }
-        }
-        __syncthreads();
+    issue_body(0, 0, tph);
 
-        const v2f *__restrict__ t = reinterpret_cast<const v2f *>(tbl + tph);   // wave-uniform -> scalar loads
+    for (int b = 0; b < n_bodies; b++) {
+        // body b's tile has landed (this wave's DMA: vmcnt; everybody's: barrier).  The barrier also
+        // says every wave is done reading the other buffer, so the next body may be fetched into it.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         tph += SB;
         if (tph >= a.N) tph -= a.N;
+        if (b + 1 < n_bodies) issue_body(b + 1, (b + 1) & 1, tph);
+
+        const char *buf = lds + (b & 1) * G::buf_bytes;
+        const v4f *__restrict__ xrow = reinterpret_cast<const v4f *>(buf + lane * G::row_bytes);
+        const v4f *__restrict__ trow = reinterpret_cast<const v4f *>(buf + (kWave + wave) * G::row_bytes);
+
+        // LDS -> registers for stage-1 output k (samples k*M1 .. k*M1+M1-1), 16-byte reads only; when a
+        // region starts on an odd sample its first sample is the overhang (.zw) of the previous region's
+        // last read, kept in `carry`.
+        auto load_region = [&](const v4f *__restrict__ row, int k, v2f (&f)[M1], v2f &carry) {
+            const int idx0 = k * M1;
+            int first = idx0;
+            if (idx0 & 1) {
+                f[0] = carry;
+                first = idx0 + 1;
+            }
+#pragma unroll
+            for (int j = first; j < idx0 + M1; j += 2) {
+                const v4f v = row[j >> 1];
+                f[j - idx0] = v.xy;
+                if (j + 1 < idx0 + M1) f[j + 1 - idx0] = v.zw;
+                else carry = v.zw;
+            }
+        };
+
+        v2f cx = {0.f, 0.f}, ct = {0.f, 0.f};
+        v2f fx[2][M1];                 // input samples: region k+1 is fetched while region k is computed
+        v2f ft[M1];                    // translator entries (broadcast reads): fetched one region ahead too,
+                                       // but consumed first, so one buffer is enough
+        load_region(xrow, 0, fx[0], cx);
+        load_region(trow, 0, ft, ct);
 
         v2f y2v[Y2B];
 #pragma unroll
         for (int q = 0; q < Y2B; q++) {
-            // keep the scheduler from hoisting every LDS/scalar load of the body to its top
-            // (that costs > 256 VGPRs and SGPR spills); one stage-1 output is one scheduling region
-            __builtin_amdgcn_sched_barrier(0);
             v2f win2[T2];
 #pragma unroll
             for (int i = 0; i < C2; i++) win2[i] = w2c[i];
 #pragma unroll
             for (int u = 0; u < M2; u++) {
-                // M1 new mixed samples -> one stage-1 output
+                const int k = q * M2 + u;
+                // the scheduling barriers keep the compiler from hoisting all reads of the body
+                // (VGPR blow-up) and fix the software pipeline: mix region k, then fetch region k+1
+                // (LDS latency hides behind the FIR arithmetic), then the FIR of region k
                 __builtin_amdgcn_sched_barrier(0);
                 v2f win[T1];
 #pragma unroll
                 for (int i = 0; i < C1; i++) win[i] = w1c[i];
 #pragma unroll
-                for (int e = 0; e < M1; e++) {
-                    const int idx = (q * M2 + u) * M1 + e;
-                    const v4f xx = xrow[idx >> 1];
-                    const v2f xv = (idx & 1) ? xx.zw : xx.xy;
-                    win[C1 + e] = cmul_pk(xv, t[idx]);
+                for (int e = 0; e < M1; e++) win[C1 + e] = cmul_pk(fx[k & 1][e], ft[e]);
+#pragma unroll
+                for (int e = 0; e < M1; e++) asm volatile("" : "+v"(win[C1 + e]));
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < NY1) {
+                    load_region(xrow, k + 1, fx[(k + 1) & 1], cx);
+                    load_region(trow, k + 1, ft, ct);
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 win2[C2 + u] = folded_fir_pk<T1>(win, taps.h1);
                 // pin the stage-1 output here: without it LLVM sinks the arithmetic down to the
                 // stage-2 FIR and every LDS read of the body stays live (spills)
@@ -449,14 +522,14 @@ __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
     a.state[ch] = make_float4(st.g, st.pw, st.gl, st.pl);
 }
 
-// copy the last `hist` samples of [0, hist + n_new) to the front (ranges may overlap)
-__global__ void k_roll_history(float2 *x, int hist, int n_new)
+// move x[src_off .. src_off+cnt) to x[0 .. cnt) (ranges may overlap; cnt <= 256)
+__global__ void k_roll_history(float2 *x, int src_off, int cnt)
 {
     const int i = threadIdx.x;
     float2 v = make_float2(0.f, 0.f);
-    if (i < hist) v = x[n_new + i];
+    if (i < cnt) v = x[src_off + i];
     __syncthreads();
-    if (i < hist) x[i] = v;
+    if (i < cnt) x[i] = v;
 }
 
 }  // namespace sdrxgpu

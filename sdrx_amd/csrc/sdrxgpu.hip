@@ -117,9 +117,9 @@ static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
     for (int i = 0; i < (T1 + 1) / 2; i++) taps.h1[i] = L.h1[i];
     for (int i = 0; i < (T2 + 1) / 2; i++) taps.h2[i] = L.h2[i];
     switch (L.W) {
+        case 16: hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, 16>), dim3(L.grid), dim3(1024), 0, s, L.x, L.tables, L.y2, L.args, taps); break;
         case 8: hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, 8>), dim3(L.grid), dim3(512), 0, s, L.x, L.tables, L.y2, L.args, taps); break;
         case 4: hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, 4>), dim3(L.grid), dim3(256), 0, s, L.x, L.tables, L.y2, L.args, taps); break;
-        case 2: hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, 2>), dim3(L.grid), dim3(128), 0, s, L.x, L.tables, L.y2, L.args, taps); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -189,6 +189,7 @@ struct sdrxgpu_bank {
 
     // stream position
     uint64_t n_in = 0, n_out = 0;
+    long long x_origin = 0;          // absolute sample index held at d_x[0] (same parity as the next call's s0)
 
     // profiling
     bool prof = false;
@@ -239,6 +240,7 @@ static int init_state(sdrxgpu_bank *b)
     HIPCHK(hipStreamSynchronize(b->stream));
     b->n_in = 0;
     b->n_out = 0;
+    b->x_origin = -(long long)b->HIST;
     return SDRXGPU_OK;
 }
 
@@ -349,7 +351,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     // bodies per lane / workgroup width: enough workgroups to fill 256 CUs, otherwise as long as possible
     {
         const long long U = ((long long)max_y2 + k12->Y2B - 1) / k12->Y2B;
-        b->W = b->n_ch >= 2048 ? 8 : (b->n_ch >= 256 ? 4 : 2);
+        b->W = b->n_ch >= 2048 ? 16 : (b->n_ch >= 512 ? 8 : 4);
         int best = 1;
         for (int nb = b->bps; nb >= 1; nb--) {
             if (b->bps % nb) continue;
@@ -386,11 +388,11 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     // the data (their results are dropped) still read inside the allocation]
     {
         const long long G = ((long long)max_y2 / k12->Y2B + (long long)kWave * b->bps) / ((long long)kWave * b->bps) + 1;
-        b->x_capacity = (size_t)b->HIST + b->max_chunk + (size_t)G * kWave * b->spacing + (size_t)(b->WU + 2) * b->SB;
+        b->x_capacity = (size_t)b->HIST + 2 + b->max_chunk + (size_t)G * kWave * b->spacing + (size_t)(b->WU + 2) * b->SB;
     }
     int rc;
     if ((rc = dev_alloc(b, (void **)&b->d_x, b->x_capacity * sizeof(float2))) ||
-        (rc = dev_alloc(b, (void **)&b->d_tables, (size_t)b->n_ch * b->tbl_stride * sizeof(float2))) ||
+        (rc = dev_alloc(b, (void **)&b->d_tables, 2 * (size_t)b->n_ch * b->tbl_stride * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_y2, (size_t)b->n_ch * b->y2_stride * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_hist[0], (size_t)b->n_ch * b->y2_hist * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_hist[1], (size_t)b->n_ch * b->y2_hist * sizeof(float2))) ||
@@ -402,18 +404,22 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     }
 
     // translator tables: the caller's entries verbatim, wrapped by SB entries so a body never
-    // wraps; a channel without translator gets the unit table (x * (1+0j) == x exactly).
+    // wraps; a channel without translator gets the unit table (x * (1+0j) == x exactly).  Two copies:
+    // copy 0 starts at t[0], copy 1 at t[1], so that a body's first entry is always at an even index
+    // (16-byte aligned LDS-DMA source) whatever the parity of the stream position.
     {
-        std::vector<float2> host((size_t)b->n_ch * b->tbl_stride);
-        for (uint32_t c = 0; c < b->n_ch; c++) {
-            float2 *row = host.data() + (size_t)c * b->tbl_stride;
-            const sdrxgpu_channel &ch = cfg->channels[c];
-            for (int i = 0; i < b->tbl_stride; i++) {
-                if (ch.n_translator) {
-                    const sdrxgpu_iq &t = ch.translator[i % b->Neff];
-                    row[i] = make_float2(t.re, t.im);
-                } else {
-                    row[i] = make_float2(1.0f, 0.0f);
+        std::vector<float2> host(2 * (size_t)b->n_ch * b->tbl_stride);
+        for (int copy = 0; copy < 2; copy++) {
+            for (uint32_t c = 0; c < b->n_ch; c++) {
+                float2 *row = host.data() + ((size_t)copy * b->n_ch + c) * b->tbl_stride;
+                const sdrxgpu_channel &ch = cfg->channels[c];
+                for (int i = 0; i < b->tbl_stride; i++) {
+                    if (ch.n_translator) {
+                        const sdrxgpu_iq &t = ch.translator[(i + copy) % b->Neff];
+                        row[i] = make_float2(t.re, t.im);
+                    } else {
+                        row[i] = make_float2(1.0f, 0.0f);
+                    }
                 }
             }
         }
@@ -478,7 +484,7 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
 extern "C" int sdrxgpu_bank_ingest_buffer(sdrxgpu_bank *b, void **d_ptr, size_t *capacity)
 {
     if (!b || !d_ptr) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_ingest_buffer: null argument");
-    *d_ptr = b->d_x + b->HIST;
+    *d_ptr = b->d_x + ((long long)b->n_in - b->x_origin);
     if (capacity) *capacity = b->max_chunk;
     return SDRXGPU_OK;
 }
@@ -597,7 +603,9 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         const long long s0 = j0 * b->MM;                               // abs index of the first input of y2[j0]
         const long long first = s0 - (long long)b->WU * b->SB;         // first warm-up sample of lane 0
         L.x = b->d_x;
-        L.tables = b->d_tables;
+        const long long tph_abs = ((first % b->Neff) + b->Neff) % b->Neff;  // trans_pos_ of that sample (msd.hpp:135)
+        const int tcopy = (int)(tph_abs & 1);                              // odd phase: table copy shifted by one entry
+        L.tables = b->d_tables + (size_t)tcopy * b->n_ch * b->tbl_stride;
         L.y2 = b->d_y2;
         a.n_ch = (int)b->n_ch;
         a.tbl_stride = b->tbl_stride;
@@ -606,21 +614,23 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         a.y2_stride = b->y2_stride;
         a.y2_hist = 0;                                                 // new outputs start at row index 0
         a.n_y2_new = n_y2_new;
-        a.x_base = (int)(first - (n0 - b->HIST));                      // d_x[0] holds abs sample n0 - HIST
-        a.tphase0 = (int)(((first % b->Neff) + b->Neff) % b->Neff);    // trans_pos_ of that sample (msd.hpp:135)
+        a.x_base = (int)(first - b->x_origin);                         // d_x[0] holds abs sample x_origin
+        a.tphase0 = (int)(tph_abs - tcopy);
         a.nb = b->nb;
         a.P = b->P;
         const long long U = ((long long)n_y2_new + k->Y2B - 1) / k->Y2B;
         const long long G = (U + (long long)kWave * b->bps - 1) / ((long long)kWave * b->bps);
         a.n_wt = (int)(G * b->P);
         a.n_chgroups = (int)((b->n_ch + b->W - 1) / b->W);
-        if (a.x_base < 0) return fail(SDRXGPU_ERR_HIP, "internal: x_base %d < 0", a.x_base);
+        a.n_cgx = (a.n_chgroups + 7) / 8 * 8;
+        if (a.x_base < 0 || (a.x_base & 1) || (a.tphase0 & 1))
+            return fail(SDRXGPU_ERR_HIP, "internal: x_base %d / tphase0 %d must be even and >= 0", a.x_base, a.tphase0);
         const size_t x_need = (size_t)a.x_base + (size_t)G * kWave * b->spacing + (size_t)(b->WU + 1) * b->SB;
         if (x_need > b->x_capacity) return fail(SDRXGPU_ERR_HIP, "internal: input ring too small (%zu > %zu)", x_need, b->x_capacity);
         L.h1 = b->taps[0].data();
         L.h2 = b->taps[1].data();
         L.W = b->W;
-        L.grid = a.n_chgroups * a.n_wt;
+        L.grid = a.n_cgx * a.n_wt;
         {
             ProfScope ps(b, SDRXGPU_K_STAGE12);
             HIPCHK(k->fn(L, b->stream));
@@ -706,9 +716,20 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         b->n_out += (uint64_t)t.n_b;
     }
 
-    // keep the last HIST input samples in front of the next block
-    hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(256), 0, b->stream, b->d_x, b->HIST, (int)in_len);
-    HIPCHK(hipGetLastError());
+    // keep the last HIST (+1 when the next call's first body would otherwise start on an odd index)
+    // input samples in front of the next block
+    {
+        const long long n1b = n0 + (long long)in_len;
+        const long long s0_next = (n1b / b->MM) * b->MM;
+        long long origin_next = n1b - b->HIST;
+        if ((origin_next - s0_next) & 1) origin_next -= 1;
+        const int src_off = (int)(origin_next - b->x_origin);
+        const int cnt = (int)(n1b - origin_next);
+        if (src_off < 0) return fail(SDRXGPU_ERR_HIP, "internal: history roll offset %d < 0", src_off);
+        hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(256), 0, b->stream, b->d_x, src_off, cnt);
+        HIPCHK(hipGetLastError());
+        b->x_origin = origin_next;
+    }
     b->n_in += in_len;
     return SDRXGPU_OK;
 }
@@ -718,14 +739,14 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "process: null bank");
     if (in_len && !in) return fail(SDRXGPU_ERR_INVALID_ARG, "process: null input");
-    if (b->HIST > 256) return fail(SDRXGPU_ERR_UNSUPPORTED, "internal: history %d > 256", b->HIST);
+    if (b->HIST + 1 > 256) return fail(SDRXGPU_ERR_UNSUPPORTED, "internal: history %d > 255", b->HIST);
     HIPCHK(hipSetDevice(b->device));
     ProfScope total(b, SDRXGPU_K_TOTAL);
 
     const float2 *src = (const float2 *)in;
     size_t done = 0, produced_total = 0;
-    float2 *d_ingest = b->d_x + b->HIST;
     while (done < in_len) {
+        float2 *d_ingest = b->d_x + ((long long)b->n_in - b->x_origin);
         const size_t n = std::min(in_len - done, (size_t)b->max_chunk);
         if (in_is_host) {
             HIPCHK(hipMemcpyAsync(d_ingest, src + done, n * sizeof(float2), hipMemcpyHostToDevice, b->stream));
