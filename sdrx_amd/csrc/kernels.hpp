@@ -90,15 +90,25 @@ __device__ __forceinline__ v2f cmul_pk(v2f x, v2f t)
     return r;
 }
 
+// Folded symmetric FIR, packed.  Two interleaved accumulators (even / odd tap pairs) so that no
+// packed instruction reads the result of the instruction right before it (that adjacency costs a
+// wait state on gfx950); the two partial sums are added at the end.  Same products as the
+// reference's folded form (msd.hpp:309-331), summed in a different order (fp32 rounding only).
 template <int T>
 __device__ __forceinline__ v2f folded_fir_pk(const v2f (&w)[T], const float *__restrict__ h)
 {
     constexpr int half = (T - 1) / 2;
-    v2f acc = (w[0] + w[T - 1]) * v2f{h[0], h[0]};
+    v2f s[half];
 #pragma unroll
-    for (int i = 1; i < half; i++) acc = __builtin_elementwise_fma(w[i] + w[T - 1 - i], v2f{h[i], h[i]}, acc);
-    acc = __builtin_elementwise_fma(w[half], v2f{h[half], h[half]}, acc);
-    return acc;
+    for (int i = 0; i < half; i++) s[i] = w[i] + w[T - 1 - i];
+    v2f acc0 = s[0] * v2f{h[0], h[0]};
+    v2f acc1 = w[half] * v2f{h[half], h[half]};
+#pragma unroll
+    for (int i = 1; i < half; i++) {
+        if (i & 1) acc1 = __builtin_elementwise_fma(s[i], v2f{h[i], h[i]}, acc1);
+        else       acc0 = __builtin_elementwise_fma(s[i], v2f{h[i], h[i]}, acc0);
+    }
+    return acc0 + acc1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -132,14 +142,18 @@ struct Stage12Args {
     int n_cgx;              // n_chgroups rounded up to a multiple of 8 (XCD-aware block map)
 };
 
-// LDS tile geometry.  One buffer = 64 input rows (one per lane / time segment) + W translator rows
-// (one per wave / channel), every row SB samples (8 B each) + 16 B pad.  The pad keeps rows 16-byte
+// LDS tile geometry.  A wave's 64 lanes are CPW channels x SPW = 64/CPW time segments (lane =
+// csub * SPW + segment); the W waves of a workgroup cover the same SPW segments for W*CPW channels.
+// One buffer = SPW input rows (one per time segment) + W*CPW translator rows (one per channel),
+// every row SB samples (8 B each) + 16 B pad.  The pad keeps rows 16-byte
 // aligned and makes the row pitch (2*SB+4 dwords) fall on distinct 4-bank slots within each 16-lane
 // group of a ds_read_b128 (conflict-free row-per-lane reads; translator rows are read as broadcasts).
-template <int SB, int W>
+template <int SB, int W, int CPW>
 struct TileGeom {
     static constexpr int row_bytes = SB * 8 + 16;
-    static constexpr int rows = kWave + W;
+    static constexpr int x_rows = kWave / CPW;              // time segments per wave
+    static constexpr int t_rows = W * CPW;                  // channels per workgroup
+    static constexpr int rows = x_rows + t_rows;
     static constexpr int buf_bytes = rows * row_bytes;
     static constexpr int lanes_per_row = SB / 2;            // 16-byte DMA pieces per row
 };
@@ -164,8 +178,8 @@ __device__ __forceinline__ void dma_row(const float2 *src_row /* wave-uniform */
     }
 }
 
-template <int M1, int T1, int M2, int T2, int Y2B, int W>
-__global__ __launch_bounds__(kWave * W, (W >= 16 ? 4 : (W >= 8 ? 2 : 1)))
+template <int M1, int T1, int M2, int T2, int Y2B, int W, int CPW>
+__global__ __launch_bounds__(kWave * W, 4)
 void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
                const Stage12Args a, const Stage12Taps<T1, T2> taps)
 {
@@ -175,17 +189,19 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
     constexpr int WU = (HALO + SB - 1) / SB;               // warm-up bodies
     constexpr int C1 = T1 - M1;                            // carried mixed samples
     constexpr int C2 = T2 - M2;                            // carried stage-1 outputs
-    using G = TileGeom<SB, W>;
-    constexpr int RPW = kWave / W;                         // input rows each wave fetches per body
+    using G = TileGeom<SB, W, CPW>;
+    constexpr int SPW = kWave / CPW;                       // time segments per wave
     static_assert(SB % 2 == 0, "body must hold an even number of samples (16-byte LDS accesses)");
     static_assert(SB >= C1 && NY1 >= C2, "a body must refresh both delay lines completely");
-    static_assert(kWave % W == 0, "W must divide 64");
+    static_assert(kWave % CPW == 0, "CPW must divide 64");
 
     __shared__ __attribute__((aligned(16))) char lds[2 * G::buf_bytes];
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int csub = lane / SPW;                           // which of the wave's CPW channels
+    const int sl = lane - csub * SPW;                      // which of the wave's SPW time segments
 
     // blockIdx -> (channel group, time-wave).  Blocks are dealt round-robin over the 8 XCDs
     // (b % 8 labels the XCD group), so the time-waves of one channel group -- which read the same
@@ -199,35 +215,35 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
     const int p = wt - g * a.P;
     const int bps = a.nb * a.P;                            // bodies per segment = spacing / SB
 
-    int ch = cg * W + wave;
+    const int ch0 = (cg * W + wave) * CPW;                 // first channel of this wave (wave-uniform)
+    const int ch = ch0 + csub;                             // this lane's channel
     const bool ch_ok = ch < a.n_ch;
-    if (!ch_ok) ch = a.n_ch - 1;                           // keeps every wave in the barriers
 
-    // first real body slot of lane 0 in this time-wave; whole workgroup leaves if it is past the end
-    const int slot0 = g * kWave * bps + a.nb * p;
+    // first real body slot of segment 0 of this time-wave; whole workgroup leaves if it is past the end
+    const int slot0 = g * SPW * bps + a.nb * p;
     if (slot0 * Y2B >= a.n_y2_new) return;
 
     int tph = a.tphase0 + p * a.nb * SB;                   // translator index at the first warm-up sample
     tph %= a.N;
-#ifdef SDRX_EXP_SAMETABLE
-    const float2 *tbl = tables;   // timing experiment only: every wave reads channel 0's table
-#else
-    const float2 *tbl = tables + (size_t)ch * a.tbl_stride;
-#endif
-    const float2 *xsrc = x_in + a.x_base + (size_t)slot0 * SB;   // lane 0, first warm-up sample
+    const float2 *xsrc = x_in + a.x_base + (size_t)slot0 * SB;   // segment 0, first warm-up sample
 
     const int n_bodies = WU + a.nb;
 
-    // issue the DMA of body `b` into LDS buffer `bi`: this wave's share of the 64 input rows + its
-    // own channel's translator row
+    // issue the DMA of body `b` into LDS buffer `bi`: this wave's share of the SPW input rows + the
+    // translator rows of its own CPW channels (a channel past the end re-reads the last one's table)
     auto issue_body = [&](int b, int bi, int tphb) {
         char *buf = lds + bi * G::buf_bytes;
-#pragma unroll
-        for (int rr = 0; rr < RPW; rr++) {
-            const int r = wave * RPW + rr;
+        for (int r = wave; r < SPW; r += W)
             dma_row<SB>(xsrc + (size_t)b * SB + (size_t)r * a.spacing, buf + r * G::row_bytes, lane);
+#pragma unroll
+        for (int c = 0; c < CPW; c++) {
+#ifdef SDRX_EXP_SAMETABLE
+            const int tc = 0;   // timing experiment only: every wave reads channel 0's table
+#else
+            const int tc = min(ch0 + c, a.n_ch - 1);
+#endif
+            dma_row<SB>(tables + (size_t)tc * a.tbl_stride + tphb, buf + (SPW + wave * CPW + c) * G::row_bytes, lane);
         }
-        dma_row<SB>(tbl + tphb, buf + (kWave + wave) * G::row_bytes, lane);
     };
 
     v2f w1c[C1];   // last C1 mixed samples        (stage-1 delay line, newest last)
@@ -238,9 +254,25 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
     for (int i = 0; i < C2; i++) w2c[i] = v2f{0.f, 0.f};
 
     // y2 destination of this lane's first real output
-    const int seg = g * kWave + lane;
+    const int seg = g * SPW + sl;
     int jrel = (seg * bps + a.nb * p) * Y2B;
-    float2 *__restrict__ ydst = y2_out + (size_t)ch * a.y2_stride + a.y2_hist;
+    float2 *__restrict__ ydst = y2_out + (size_t)(ch_ok ? ch : 0) * a.y2_stride + a.y2_hist;
+
+    // a lane's Y2B outputs of one body are contiguous in its channel's row: 16-byte stores when the
+    // whole group is valid (rows are 16-byte aligned and jrel is a multiple of Y2B)
+    v2f y2v[Y2B];
+    auto store_y2 = [&](int j) {
+        if (!ch_ok) return;
+        if (Y2B % 2 == 0 && j + Y2B <= a.n_y2_new) {
+#pragma unroll
+            for (int q = 0; q < Y2B; q += 2)
+                *reinterpret_cast<v4f *>(ydst + j + q) = v4f{y2v[q].x, y2v[q].y, y2v[q + 1].x, y2v[q + 1].y};
+        } else {
+#pragma unroll
+            for (int q = 0; q < Y2B; q++)
+                if (j + q < a.n_y2_new) ydst[j + q] = make_float2(y2v[q].x, y2v[q].y);
+        }
+    };
 
     issue_body(0, 0, tph);
 
@@ -249,13 +281,20 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
         // says every wave is done reading the other buffer, so the next body may be fetched into it.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // the previous body's outputs are stored HERE, not at the end of that body: the vmcnt(0)
+        // above would otherwise wait for the store round trip every body; now the stores are a whole
+        // body old by the time the next wait comes
+        if (b > WU) {
+            store_y2(jrel);
+            jrel += Y2B;
+        }
         tph += SB;
         if (tph >= a.N) tph -= a.N;
         if (b + 1 < n_bodies) issue_body(b + 1, (b + 1) & 1, tph);
 
         const char *buf = lds + (b & 1) * G::buf_bytes;
-        const v4f *__restrict__ xrow = reinterpret_cast<const v4f *>(buf + lane * G::row_bytes);
-        const v4f *__restrict__ trow = reinterpret_cast<const v4f *>(buf + (kWave + wave) * G::row_bytes);
+        const v4f *__restrict__ xrow = reinterpret_cast<const v4f *>(buf + sl * G::row_bytes);
+        const v4f *__restrict__ trow = reinterpret_cast<const v4f *>(buf + (SPW + wave * CPW + csub) * G::row_bytes);
 
         // LDS -> registers for stage-1 output k (samples k*M1 .. k*M1+M1-1), 16-byte reads only; when a
         // region starts on an odd sample its first sample is the overhang (.zw) of the previous region's
@@ -283,7 +322,6 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
         load_region(xrow, 0, fx[0], cx);
         load_region(trow, 0, ft, ct);
 
-        v2f y2v[Y2B];
 #pragma unroll
         for (int q = 0; q < Y2B; q++) {
             v2f win2[T2];
@@ -322,15 +360,8 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
             for (int i = 0; i < C2; i++) w2c[i] = win2[i + M2];
         }
 
-        if (b >= WU) {
-            if (ch_ok) {
-#pragma unroll
-                for (int q = 0; q < Y2B; q++)
-                    if (jrel + q < a.n_y2_new) ydst[jrel + q] = make_float2(y2v[q].x, y2v[q].y);
-            }
-            jrel += Y2B;
-        }
     }
+    store_y2(jrel);       // the last body's outputs (n_bodies > WU always)
 }
 
 // ------------------------------------------------------------------------------------------

@@ -104,7 +104,7 @@ struct K12Launch {
     float2 *y2;
     Stage12Args args;
     const float *h1, *h2;
-    int W;
+    int W, CPW;
     int grid;
 };
 
@@ -116,13 +116,17 @@ static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
     Stage12Taps<T1, T2> taps;
     for (int i = 0; i < (T1 + 1) / 2; i++) taps.h1[i] = L.h1[i];
     for (int i = 0; i < (T2 + 1) / 2; i++) taps.h2[i] = L.h2[i];
-    switch (L.W) {
-        case 16: hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, 16>), dim3(L.grid), dim3(1024), 0, s, L.x, L.tables, L.y2, L.args, taps); break;
-        case 8: hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, 8>), dim3(L.grid), dim3(512), 0, s, L.x, L.tables, L.y2, L.args, taps); break;
-        case 4: hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, 4>), dim3(L.grid), dim3(256), 0, s, L.x, L.tables, L.y2, L.args, taps); break;
-        default: return hipErrorInvalidValue;
+#define SDRX_K12_CASE(W_, C_)                                                                                  \
+    if (L.W == W_ && L.CPW == C_) {                                                                             \
+        hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, W_, C_>), dim3(L.grid), dim3(64 * W_), 0, s, L.x,    \
+                           L.tables, L.y2, L.args, taps);                                                       \
+        return hipGetLastError();                                                                               \
     }
-    return hipGetLastError();
+    SDRX_K12_CASE(16, 4) SDRX_K12_CASE(16, 2) SDRX_K12_CASE(16, 1)
+    SDRX_K12_CASE(8, 4) SDRX_K12_CASE(8, 2) SDRX_K12_CASE(8, 1)
+    SDRX_K12_CASE(4, 4) SDRX_K12_CASE(4, 2) SDRX_K12_CASE(4, 1)
+#undef SDRX_K12_CASE
+    return hipErrorInvalidValue;
 }
 
 struct K12Entry {
@@ -170,7 +174,7 @@ struct sdrxgpu_bank {
     int MM = 1, SB = 1, WU = 1, HIST = 0;
     int Neff = 0;                    // table length on the device (N, or SB*12 when nobody mixes)
     int spacing = 0, bps = 0;        // lane spacing in samples, bodies per segment
-    int nb = 0, P = 0, W = 8;
+    int nb = 0, P = 0, W = 16, CPW = 4;
     int tbl_stride = 0;
     int y2_hist = 0, y2_stride = 0;
     uint32_t max_chunk = 0;
@@ -348,20 +352,50 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         }
     }
 
-    // bodies per lane / workgroup width: enough workgroups to fill 256 CUs, otherwise as long as possible
+    // Geometry of the stage-1/2 launch: W waves per workgroup, CPW channels per wave (the wave's 64
+    // lanes are CPW channels x 64/CPW time segments), nb bodies per lane.  Every choice computes the same
+    // outputs bit for bit (tests/test_gpu_parity.py); the choice only decides how much of the machine does
+    // useful work.  Picked by a small model of one standard block: useful lane-bodies / (lane-bodies the
+    // grid occupies, in whole rounds of resident workgroups), times how well the CU's SIMDs are fed.
     {
-        const long long U = ((long long)max_y2 + k12->Y2B - 1) / k12->Y2B;
-        b->W = b->n_ch >= 2048 ? 16 : (b->n_ch >= 512 ? 8 : 4);
-        int best = 1;
-        for (int nb = b->bps; nb >= 1; nb--) {
-            if (b->bps % nb) continue;
-            const int P = b->bps / nb;
-            const long long G = (U + (long long)kWave * b->bps - 1) / ((long long)kWave * b->bps);
-            const long long wgs = (long long)((b->n_ch + b->W - 1) / b->W) * G * P;
-            best = nb;
-            if (wgs >= 1024) break;
+        const long long U = ((long long)max_y2 + k12->Y2B - 1) / k12->Y2B;      // body slots per channel per call
+        double best_score = -1.0;
+        const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        for (int W : {16, 8, 4}) {
+            for (int CPW : {4, 2, 1}) {
+                const int SPW = kWave / CPW;
+                const size_t lds = 2 * (size_t)(SPW + W * CPW) * (b->SB * 8 + 16);
+                if (lds > 160 * 1024) continue;
+                int wg_per_cu = (int)std::min<size_t>(160 * 1024 / lds, (size_t)(16 / W));   // <= 4 waves/SIMD (128 VGPRs)
+                if (wg_per_cu < 1) continue;
+                const double waves_per_simd = wg_per_cu * W / 4.0;
+                const double feed = std::min(1.0, 0.35 + 0.325 * waves_per_simd);          // 1 wave/SIMD ~ 2/3 of peak issue
+                for (int nb = b->bps; nb >= 1; nb--) {
+                    if (b->bps % nb) continue;
+                    const int P = b->bps / nb;
+                    const long long G = (U + (long long)SPW * b->bps - 1) / ((long long)SPW * b->bps);
+                    const long long cgs = ((long long)b->n_ch + W * CPW - 1) / (W * CPW);
+                    const long long wgs = cgs * G * P;
+                    const long long slots = (long long)n_cu * wg_per_cu;
+                    const long long rounds = (wgs + slots - 1) / slots;
+                    const double useful = (double)b->n_ch * (double)U;                       // lane-bodies that produce output
+                    const double spent = (double)rounds * slots * W * kWave * (b->WU + nb);
+                    const double score = useful / spent * feed;
+                    if (score > best_score * 1.0001) {
+                        best_score = score;
+                        b->W = W;
+                        b->CPW = CPW;
+                        b->nb = nb;
+                    }
+                }
+            }
         }
-        b->nb = best;
+        if (const char *e = getenv("SDRXGPU_K12_W")) b->W = atoi(e);
+        if (const char *e = getenv("SDRXGPU_K12_CPW")) b->CPW = atoi(e);
+        if (!((b->W == 16 || b->W == 8 || b->W == 4) && (b->CPW == 4 || b->CPW == 2 || b->CPW == 1))) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: SDRXGPU_K12_W/CPW must be 4|8|16 and 1|2|4");
+        }
         if (cfg->block_hint) {
             if (b->bps % cfg->block_hint) {
                 free_bank(b);
@@ -387,8 +421,9 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     // input ring: [HIST history | up to max_chunk new | slack so that the lanes past the end of
     // the data (their results are dropped) still read inside the allocation]
     {
-        const long long G = ((long long)max_y2 / k12->Y2B + (long long)kWave * b->bps) / ((long long)kWave * b->bps) + 1;
-        b->x_capacity = (size_t)b->HIST + 2 + b->max_chunk + (size_t)G * kWave * b->spacing + (size_t)(b->WU + 2) * b->SB;
+        const int SPW = kWave / b->CPW;
+        const long long G = ((long long)max_y2 / k12->Y2B + (long long)SPW * b->bps) / ((long long)SPW * b->bps) + 1;
+        b->x_capacity = (size_t)b->HIST + 2 + b->max_chunk + (size_t)G * SPW * b->spacing + (size_t)(b->WU + 2) * b->SB;
     }
     int rc;
     if ((rc = dev_alloc(b, (void **)&b->d_x, b->x_capacity * sizeof(float2))) ||
@@ -619,17 +654,19 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         a.nb = b->nb;
         a.P = b->P;
         const long long U = ((long long)n_y2_new + k->Y2B - 1) / k->Y2B;
-        const long long G = (U + (long long)kWave * b->bps - 1) / ((long long)kWave * b->bps);
+        const int SPW = kWave / b->CPW;
+        const long long G = (U + (long long)SPW * b->bps - 1) / ((long long)SPW * b->bps);
         a.n_wt = (int)(G * b->P);
-        a.n_chgroups = (int)((b->n_ch + b->W - 1) / b->W);
+        a.n_chgroups = (int)((b->n_ch + b->W * b->CPW - 1) / (b->W * b->CPW));
         a.n_cgx = (a.n_chgroups + 7) / 8 * 8;
         if (a.x_base < 0 || (a.x_base & 1) || (a.tphase0 & 1))
             return fail(SDRXGPU_ERR_HIP, "internal: x_base %d / tphase0 %d must be even and >= 0", a.x_base, a.tphase0);
-        const size_t x_need = (size_t)a.x_base + (size_t)G * kWave * b->spacing + (size_t)(b->WU + 1) * b->SB;
+        const size_t x_need = (size_t)a.x_base + (size_t)G * SPW * b->spacing + (size_t)(b->WU + 1) * b->SB;
         if (x_need > b->x_capacity) return fail(SDRXGPU_ERR_HIP, "internal: input ring too small (%zu > %zu)", x_need, b->x_capacity);
         L.h1 = b->taps[0].data();
         L.h2 = b->taps[1].data();
         L.W = b->W;
+        L.CPW = b->CPW;
         L.grid = a.n_cgx * a.n_wt;
         {
             ProfScope ps(b, SDRXGPU_K_STAGE12);

@@ -71,6 +71,26 @@ def test_every_time_tiling_gives_the_same_answer(hint):
     bank.close()
 
 
+@pytest.mark.parametrize("w,cpw", [(16, 4), (16, 2), (16, 1), (8, 4), (8, 1), (4, 4), (4, 2), (4, 1)])
+def test_every_workgroup_geometry_gives_the_same_answer(w, cpw, monkeypatch):
+    """Waves per workgroup / channels per wave of the stage-1/2 kernel must not show in the result."""
+    ch = chains.chain("10")
+    offs = list(range(-40, 37))            # 77 channels: not a multiple of any W*CPW
+    tabs = sb.translators_for(ch, offs)
+    blocks = [synth.synth_iq(8, b * ch.block_len, ch.block_len, 0.25) for b in range(2)]
+    ref_bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    monkeypatch.setenv("SDRXGPU_K12_W", str(w))
+    monkeypatch.setenv("SDRXGPU_K12_CPW", str(cpw))
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=4)
+    for x in blocks:
+        a, b = ref_bank.process(x)
+        c, d = bank.process(x)
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+        assert np.array_equal(b.view(np.uint32), d.view(np.uint32))
+    ref_bank.close()
+    bank.close()
+
+
 def _oracle_bank(oracle, ch, tabs, blocks, threads=8):
     ob = oracle.bank(tabs, ch.stage_tuples())
     outs = [ob.process(x, threads=threads) for x in blocks]
