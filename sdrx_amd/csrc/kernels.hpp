@@ -409,8 +409,17 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     __shared__ float hA[kMaxHalfTaps], hB[kMaxHalfTaps];
 
-    const int ch = blockIdx.x / a.n_tiles;
-    const int q = blockIdx.x - ch * a.n_tiles;
+    // blockIdx -> (channel, tile): the tiles of one channel share b % 8 (= one XCD's L2 under the
+    // round-robin block placement) and follow each other, so a tile's FIR history -- the tail of the
+    // previous tile's span -- is an L2 hit, not a second HBM read.
+    const int xcd = blockIdx.x & 7;
+    const int qq = blockIdx.x >> 3;
+    const int q = qq % a.n_tiles;
+    const int chf = (qq / a.n_tiles) * 8 + xcd;
+    if (chf >= a.n_ch) return;
+    // channels are walked from the last to the first: the stage-1/2 kernel wrote the high channel
+    // groups last, so their rows are the ones still held by the Infinity Cache / L2
+    const int ch = a.n_ch - 1 - chf;
     const int tid = threadIdx.x;
     const float2 *__restrict__ ynew = a.y2_new + (size_t)ch * a.y2_stride;
     const float2 *__restrict__ hin = a.hist_in + (size_t)ch * a.hist;
@@ -444,13 +453,26 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
         p0 = a.pB0 + a.mB * s0;
         np = a.mB * (nbt - 1) + a.tB;
     }
-    v2f *s2 = reinterpret_cast<v2f *>(smem);               // [np]
-    v2f *s3 = s2 + np;                                     // [nr]
+    // stage the span with 16-byte loads: start on an even row index (hist is even and both rows are
+    // 16-byte aligned, so a pair never straddles the hist|new seam)
+    const int p0a = p0 & ~1;
+    const int odd = p0 - p0a;
+    const int npair = (np + odd + 1) >> 1;
+    v4f *s2v = reinterpret_cast<v4f *>(smem);              // [npair] pairs
+    v2f *s2 = reinterpret_cast<v2f *>(smem) + odd;         // sample i of the span
+    v2f *s3 = reinterpret_cast<v2f *>(smem) + 2 * npair;   // stage-A outputs, after the span
 
-    for (int i = tid; i < np; i += blockDim.x) {
-        const int p = p0 + i;
-        const float2 v = p < a.hist ? hin[p] : ynew[p - a.hist];
-        s2[i] = v2f{v.x, v.y};
+    const int n_row = a.hist + a.n_y2_new;                 // valid row entries
+    for (int i = tid; i < npair; i += blockDim.x) {
+        const int p = p0a + 2 * i;
+        v4f v;
+        if (p + 1 < n_row) {
+            v = p < a.hist ? *reinterpret_cast<const v4f *>(hin + p) : *reinterpret_cast<const v4f *>(ynew + (p - a.hist));
+        } else {                                           // last pair may reach one entry past the data
+            const float2 lo = p < n_row ? (p < a.hist ? hin[p] : ynew[p - a.hist]) : make_float2(0.f, 0.f);
+            v = v4f{lo.x, lo.y, 0.f, 0.f};
+        }
+        s2v[i] = v;
     }
     __syncthreads();
 
@@ -460,11 +482,27 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
         __syncthreads();
         bsrc = s3;
     }
-    for (int s = tid; s < nbt; s += blockDim.x) {
-        const v2f y = folded_fir_lds(bsrc + a.mB * s, a.tB, hB);
-        const float2 o = make_float2(y.x, y.y);
-        if (a.iq_out) a.iq_out[(size_t)ch * a.out_stride + s0 + s] = o;
-        a.iq_keep[(size_t)ch * a.keep_stride + s0 + s] = o;
+    // stage B: two lanes per output, each takes half of the folded tap pairs; the halves meet through
+    // one cross-lane add (DPP), so all 256 threads work on 128 outputs
+    {
+        const int s = tid >> 1;
+        const int hsel = tid & 1;
+        const int half = (a.tB - 1) >> 1;
+        const int split = (half + 1) >> 1;                 // lane 0: pairs [0, split); lane 1: [split, half) + centre
+        v2f acc = {0.f, 0.f};
+        if (s < nbt) {
+            const v2f *w = bsrc + a.mB * s;
+            const int i0 = hsel ? split : 0, i1 = hsel ? half : split;
+            for (int i = i0; i < i1; i++) acc = __builtin_elementwise_fma(w[i] + w[a.tB - 1 - i], v2f{hB[i], hB[i]}, acc);
+            if (hsel) acc = __builtin_elementwise_fma(w[half], v2f{hB[half], hB[half]}, acc);
+        }
+        acc.x += __shfl_xor(acc.x, 1);
+        acc.y += __shfl_xor(acc.y, 1);
+        if (s < nbt && hsel == 0) {
+            const float2 o = make_float2(acc.x, acc.y);
+            if (a.iq_out) a.iq_out[(size_t)ch * a.out_stride + s0 + s] = o;
+            a.iq_keep[(size_t)ch * a.keep_stride + s0 + s] = o;
+        }
     }
 }
 

@@ -185,7 +185,7 @@ struct sdrxgpu_bank {
     float2 *d_x = nullptr, *d_tables = nullptr, *d_y2 = nullptr, *d_keep = nullptr;
     float2 *d_hist[2] = {nullptr, nullptr};   // stage-2 history, ping-pong between calls
     int hist_cur = 0;
-    int tile_b = 128;                         // final outputs per k_tail workgroup
+    int tile_b = 64;                          // final outputs per k_tail workgroup (64: 8 workgroups per CU)
     size_t tail_lds = 0;
     float *d_audio_keep = nullptr;
     float4 *d_state = nullptr;
@@ -336,6 +336,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     b->keep_stride = (((int)(b->max_chunk / b->m_total) + 1 + 3) / 4) * 4;   // rows stay 16-byte aligned
 
     // LDS of one k_tail tile: the stage-2 span of tile_b outputs (+ FIR history) and its stage-A outputs
+    if (const char *e = getenv("SDRXGPU_TAIL_TILE")) b->tile_b = std::max(8, std::min(128, atoi(e)));
     {
         const int tB = (int)b->ntaps[cfg->n_stages - 1], mB = (int)b->m[cfg->n_stages - 1];
         size_t np, nr = 0;
@@ -345,7 +346,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         } else {
             np = (size_t)mB * (b->tile_b - 1) + tB;
         }
-        b->tail_lds = (np + nr) * sizeof(float2);
+        b->tail_lds = (np + 4 + nr) * sizeof(float2);     // + alignment slack of the 16-byte staging
         if (b->tail_lds > 150 * 1024) {
             free_bank(b);
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tail stages need %zu B of LDS per tile (max 153600)", b->tail_lds);
@@ -718,7 +719,7 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         t.out_stride = (int)out_stride;
         {
             ProfScope ps(b, SDRXGPU_K_TAIL);
-            hipLaunchKernelGGL(k_tail, dim3(b->n_ch * t.n_tiles), dim3(256), b->tail_lds, b->stream, t);
+            hipLaunchKernelGGL(k_tail, dim3(((b->n_ch + 7) / 8 * 8) * t.n_tiles), dim3(256), b->tail_lds, b->stream, t);
             HIPCHK(hipGetLastError());
         }
         b->hist_cur ^= 1;
