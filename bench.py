@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 from sdrx_amd import bank as sb  # noqa: E402
 from sdrx_amd import chains, synth  # noqa: E402
+from sdrx_amd import dist as sdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
@@ -84,6 +85,53 @@ def cpu_baseline(chain, seconds=12.0):
     }
 
 
+def time_bank(bank, fan, ring, rank, world, dist, L, d_iq, d_au, steps, warmup, n_ring):
+    """W untimed warm-up steps, then exactly `steps` timed steps bracketed by synchronize + barrier."""
+    def step(i):
+        src = ring[i % n_ring] if rank == 0 else None
+        cur = fan.step(src)                   # N > 1: RCCL broadcast over xGMI of the shared IQ block
+        n = bank.process_device(cur.data_ptr(), L, d_iq.data_ptr(), d_au.data_ptr(), 512)
+        assert n == 512
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    bank.profile_reset()
+    bank.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    dt = sdist.max_over_ranks(dist, dt, device="cuda")
+    k = {}
+    for name, kid in (("k_stage12", sb.K_STAGE12), ("k_tail", sb.K_TAIL), ("k_agc", sb.K_AGC)):
+        ms, n = bank.profile_read(kid)
+        k[name] = (ms / max(n, 1), int(n))
+    bank.profile_enable(False)
+    return dt, k
+
+
+def measured_traffic(n_ch):
+    """HBM bytes per k_stage12 launch from the rocprofv3 --pmc passes of this build (tools_pmc.sh ->
+    profiles/*_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  null when no
+    profile of this channel count is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("channels") == n_ch:
+                return d.get("k_stage12_hbm_bytes_per_launch"), os.path.basename(f)
+        except (OSError, ValueError):
+            pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,12 +141,11 @@ def main():
     ap.add_argument("--rate", default="10")
     ap.add_argument("--block-hint", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = sdist.env_rank_world()
     if world != args.gpus and world > 1:
         args.gpus = world
     torch.cuda.set_device(local_rank)
@@ -109,72 +156,56 @@ def main():
 
     ch = chains.chain(args.rate)
     n_ch = args.channels
-    # this rank's shard of the job's channel list (instances cycle through all N distinct offsets; never deduplicated)
-    offs_all = chains.offsets_cycled(n_ch * world, ch.N)
-    offs = offs_all[rank * n_ch:(rank + 1) * n_ch]
-    tabs = sb.translators_for(ch, offs)
-    stream = torch.cuda.current_stream().cuda_stream
-    bank = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, stream=stream, block_hint=args.block_hint)
+    L = ch.block_len
+    # one explicit (non-default) torch stream carries everything: the ring copy, the RCCL broadcast and the
+    # bank's kernels are then ordered by stream order alone
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
 
     # synthetic IQ stream: a ring of distinct 32 ms blocks in HBM on rank 0 (uniform noise + 2 AM carriers)
     n_ring = 8
-    L = ch.block_len
     blk = torch.empty(L, 2, dtype=torch.float32, device="cuda")
     ring = None
     if rank == 0:
-        car_offs = [5, -20]
-        car = [sb.make_translator(ch.N, ch.z, o) for o in car_offs]
+        car = [sb.make_translator(ch.N, ch.z, o) for o in (5, -20)]
         host = np.stack([synth.synth_iq(1234, b * L, L, 0.25, car, [0.3, 0.1], ch.N, ch.fs // 1000).view(np.float32).reshape(L, 2)
                          for b in range(n_ring)])
         ring = torch.from_numpy(host).cuda()
-    d_iq = torch.empty(n_ch, 512, 2, dtype=torch.float32, device="cuda")
-    d_au = torch.empty(n_ch, 512, dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
+    fan = sdist.BlockFanout(dist, blk, src=0)
 
-    def step(i):
-        if rank == 0:
-            src = ring[i % n_ring]
-        if world > 1:
-            if rank == 0:
-                blk.copy_(src)
-            dist.broadcast(blk, src=0)        # RCCL over xGMI: the shared IQ block
-            p = blk.data_ptr()
-        else:
-            p = src.data_ptr()
-        n = bank.process_device(p, L, d_iq.data_ptr(), d_au.data_ptr(), 512)
-        assert n == 512
+    def run(offsets, steps, warmup):
+        tabs = sb.translators_for(ch, offsets)
+        bank = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, stream=tstream.cuda_stream, block_hint=args.block_hint)
+        d_iq = torch.empty(len(offsets), 512, 2, dtype=torch.float32, device="cuda")
+        d_au = torch.empty(len(offsets), 512, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        dt, k = time_bank(bank, fan, ring, rank, world, dist, L, d_iq, d_au, steps, warmup, n_ring)
+        assert bool(torch.isfinite(d_au).all()) and bool(torch.isfinite(d_iq).all())
+        bank.close()
+        return dt, k
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    bank.profile_reset()
-    bank.profile_enable(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    k12_ms, k12_n = bank.profile_read(sb.K_STAGE12)
-    tail_ms, tail_n = bank.profile_read(sb.K_TAIL)
-    agc_ms, agc_n = bank.profile_read(sb.K_AGC)
-    bank.profile_enable(False)
-    assert bool(torch.isfinite(d_au).all()) and bool(torch.isfinite(d_iq).all())
+    # this rank's shard of the job's channel list (instances cycle through all N distinct offsets; never deduplicated)
+    offs = sdist.shard_list(chains.offsets_cycled(n_ch * world, ch.N), rank, world)
+    assert len(offs) == n_ch
+    dt, k = run(offs, args.steps, args.warmup)
+
+    extra = {}
+    if world == 1 and not args.no_extra_configs:
+        # BASELINE.json's other single-GPU configurations, same step definition (parity-test sizes; short runs)
+        for name, key in (("64 channels, 8.33 kHz grid (configs[1])", "c2"), ("1024 channels, mixed 8.33/25 kHz (configs[2])", "c3")):
+            o = chains.offsets_for_config(key)
+            dte, ke = run(o, max(10, args.steps), args.warmup)
+            extra[name] = {"value": len(o) * L * max(10, args.steps) / dte / 1e6, "unit": "Mch-samples/s",
+                           "ms_per_step": dte / max(10, args.steps) * 1e3, "realtime_factor": L * max(10, args.steps) / dte / ch.fs,
+                           "kernel_ms_avg": {n: v[0] for n, v in ke.items()}}
 
     if rank == 0:
         total_cs = float(n_ch) * world * L * args.steps
         value = total_cs / dt / 1e6
         bpu = algorithmic_bytes_per_channel_sample(ch.m_total)
-        k12_avg_s = k12_ms / max(k12_n, 1) / 1e3
-        achieved = bpu * n_ch * L / k12_avg_s / 1e9 if k12_n else None
+        k12_ms, k12_n = k["k_stage12"]
+        achieved = bpu * n_ch * L / (k12_ms / 1e3) / 1e9 if k12_n else None
+        traffic, traffic_src = measured_traffic(n_ch)
         out = {
             "metric": "IQ Msamples/s ingested x channels demodulated (channel-samples/s)",
             "value": value, "unit": "Mch-samples/s",
@@ -195,19 +226,22 @@ def main():
                 "bound": "hbm", "kernel": "k_stage12 (mixer + stages 1-2)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bpu * n_ch * L,
-                "kernel_ms_avg": {"k_stage12": k12_ms / max(k12_n, 1), "k_tail": tail_ms / max(tail_n, 1),
-                                  "k_agc": agc_ms / max(agc_n, 1)},
+                "kernel_ms_avg": {n: v[0] for n, v in k.items()},
                 "launches": int(k12_n),
+                "note": "achieved = ALGORITHMIC bytes (8.02 B per channel-sample) / kernel time; the IQ block is shared by "
+                        "all channels on chip, so physical HBM traffic is far smaller and the kernel is bound by packed-fp32 "
+                        "VALU issue, not by HBM (DESIGN.md)",
             },
         }
+        if extra:
+            out["other_configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ch, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    bank.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -253,24 +253,28 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
 #pragma unroll
     for (int i = 0; i < C2; i++) w2c[i] = v2f{0.f, 0.f};
 
-    // y2 destination of this lane's first real output
-    const int seg = g * SPW + sl;
-    int jrel = (seg * bps + a.nb * p) * Y2B;
-    float2 *__restrict__ ydst = y2_out + (size_t)(ch_ok ? ch : 0) * a.y2_stride + a.y2_hist;
-
-    // a lane's Y2B outputs of one body are contiguous in its channel's row: 16-byte stores when the
-    // whole group is valid (rows are 16-byte aligned and jrel is a multiple of Y2B)
+    // Stage-2 outputs leave in BODY-MAJOR order: row[((wt*nb + body)*SPW + segment)*Y2B + q].  The SPW
+    // lanes of one channel then write SPW*Y2B*8 contiguous bytes per body (512 B = four whole 128-byte
+    // lines for the 10 MS/s chain) in one go.  In time order each lane would write 32 B into its own
+    // 384-byte span per body: partial lines that L2 evicts before they fill, which measured as a
+    // read-for-ownership plus two writes per byte (3 GB of HBM traffic per launch instead of 1 GB).
+    // k_tail undoes the permutation while it stages its tiles (y2_storage_index below).
+    float2 *__restrict__ ydst = y2_out + (size_t)(ch_ok ? ch : 0) * a.y2_stride + a.y2_hist
+                                + ((size_t)wt * a.nb * SPW + sl) * Y2B;
     v2f y2v[Y2B];
-    auto store_y2 = [&](int j) {
+    auto store_y2 = [&](int body) {          // body = 0 .. nb-1 (real bodies only)
         if (!ch_ok) return;
-        if (Y2B % 2 == 0 && j + Y2B <= a.n_y2_new) {
+#ifdef SDRX_EXP_NOSTORE
+        if (a.n_ch > 0) return;   // timing experiment only: arithmetic stays live, nothing is written
+#endif
+        float2 *dst = ydst + (size_t)body * SPW * Y2B;
+        if (Y2B % 2 == 0) {
 #pragma unroll
             for (int q = 0; q < Y2B; q += 2)
-                *reinterpret_cast<v4f *>(ydst + j + q) = v4f{y2v[q].x, y2v[q].y, y2v[q + 1].x, y2v[q + 1].y};
+                *reinterpret_cast<v4f *>(dst + q) = v4f{y2v[q].x, y2v[q].y, y2v[q + 1].x, y2v[q + 1].y};
         } else {
 #pragma unroll
-            for (int q = 0; q < Y2B; q++)
-                if (j + q < a.n_y2_new) ydst[j + q] = make_float2(y2v[q].x, y2v[q].y);
+            for (int q = 0; q < Y2B; q++) dst[q] = make_float2(y2v[q].x, y2v[q].y);
         }
     };
 
@@ -284,10 +288,7 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
         // the previous body's outputs are stored HERE, not at the end of that body: the vmcnt(0)
         // above would otherwise wait for the store round trip every body; now the stores are a whole
         // body old by the time the next wait comes
-        if (b > WU) {
-            store_y2(jrel);
-            jrel += Y2B;
-        }
+        if (b > WU) store_y2(b - 1 - WU);
         tph += SB;
         if (tph >= a.N) tph -= a.N;
         if (b + 1 < n_bodies) issue_body(b + 1, (b + 1) & 1, tph);
@@ -361,7 +362,7 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
         }
 
     }
-    store_y2(jrel);       // the last body's outputs (n_bodies > WU always)
+    store_y2(a.nb - 1);   // the last body's outputs
 }
 
 // ------------------------------------------------------------------------------------------
@@ -392,9 +393,28 @@ struct TailArgs {
     int n_b;                // stage-B outputs = outputs of the call
     int tile_b;             // outputs per tile
     int n_tiles;            // >= 1
+    // body-major storage of the new stage-2 outputs (see k_stage12): geometry of the launch that wrote them
+    int y2b, seg_len, ph_len, spw_shift, spw, nb, P;       // seg_len = bps*Y2B, ph_len = nb*Y2B
+    float rcp_seg_len, rcp_ph_len, rcp_y2b;
     float hA[kMaxHalfTaps];
     float hB[kMaxHalfTaps];
 };
+
+// time index j (0 = first new stage-2 output of this call) -> index in the channel's body-major row
+__device__ __forceinline__ int y2_storage_index(const TailArgs &a, int j)
+{
+    // small non-negative j: floor((j + 0.5) / d) through a float reciprocal is exact
+    const int seg = (int)(((float)j + 0.5f) * a.rcp_seg_len);
+    const int r = j - seg * a.seg_len;
+    const int pp = (int)(((float)r + 0.5f) * a.rcp_ph_len);
+    const int r2 = r - pp * a.ph_len;
+    const int body = (int)(((float)r2 + 0.5f) * a.rcp_y2b);
+    const int q = r2 - body * a.y2b;
+    const int g = seg >> a.spw_shift;
+    const int sl = seg & (a.spw - 1);
+    const int wt = g * a.P + pp;
+    return ((wt * a.nb + body) * a.spw + sl) * a.y2b + q;
+}
 
 __device__ __forceinline__ v2f folded_fir_lds(const v2f *__restrict__ w, int T, const float *__restrict__ h)
 {
@@ -434,7 +454,7 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
         float2 *__restrict__ hout = a.hist_out + (size_t)ch * a.hist;
         for (int i = tid; i < a.hist; i += blockDim.x) {
             const int idx = a.n_y2_new + i;
-            hout[i] = idx < a.hist ? hin[idx] : ynew[idx - a.hist];
+            hout[i] = idx < a.hist ? hin[idx] : ynew[y2_storage_index(a, idx - a.hist)];
         }
     }
 
@@ -466,10 +486,12 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
     for (int i = tid; i < npair; i += blockDim.x) {
         const int p = p0a + 2 * i;
         v4f v;
+        // (a pair never straddles a body's group of Y2B outputs: p - hist is even and Y2B is even)
         if (p + 1 < n_row) {
-            v = p < a.hist ? *reinterpret_cast<const v4f *>(hin + p) : *reinterpret_cast<const v4f *>(ynew + (p - a.hist));
+            v = p < a.hist ? *reinterpret_cast<const v4f *>(hin + p)
+                           : *reinterpret_cast<const v4f *>(ynew + y2_storage_index(a, p - a.hist));
         } else {                                           // last pair may reach one entry past the data
-            const float2 lo = p < n_row ? (p < a.hist ? hin[p] : ynew[p - a.hist]) : make_float2(0.f, 0.f);
+            const float2 lo = p < n_row ? (p < a.hist ? hin[p] : ynew[y2_storage_index(a, p - a.hist)]) : make_float2(0.f, 0.f);
             v = v4f{lo.x, lo.y, 0.f, 0.f};
         }
         s2v[i] = v;

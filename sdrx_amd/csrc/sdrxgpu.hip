@@ -332,7 +332,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
 
     b->max_chunk = cfg->max_in_len ? cfg->max_in_len : 512u * b->m_total;   // 32 ms block of this chain
     const int max_y2 = (int)(b->max_chunk / b->MM) + 1;
-    b->y2_stride = ((max_y2 + 63) / 64) * 64;
+    b->y2_stride = ((max_y2 + 63) / 64) * 64;    // finalised below once the launch geometry is known
     b->keep_stride = (((int)(b->max_chunk / b->m_total) + 1 + 3) / 4) * 4;   // rows stay 16-byte aligned
 
     // LDS of one k_tail tile: the stage-2 span of tile_b outputs (+ FIR history) and its stage-A outputs
@@ -424,6 +424,8 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     {
         const int SPW = kWave / b->CPW;
         const long long G = ((long long)max_y2 / k12->Y2B + (long long)SPW * b->bps) / ((long long)SPW * b->bps) + 1;
+        // body-major stage-2 rows: whole time-waves of SPW segments x bps bodies x Y2B outputs
+        b->y2_stride = (int)((G * SPW * b->bps * k12->Y2B + 63) / 64 * 64);
         b->x_capacity = (size_t)b->HIST + 2 + b->max_chunk + (size_t)G * SPW * b->spacing + (size_t)(b->WU + 2) * b->SB;
     }
     int rc;
@@ -711,6 +713,16 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         }
         t.n_b = (int)(q1 - q_prev);
         t.tile_b = b->tile_b;
+        t.y2b = k->Y2B;
+        t.seg_len = b->bps * k->Y2B;
+        t.ph_len = b->nb * k->Y2B;
+        t.spw = kWave / b->CPW;
+        t.spw_shift = (t.spw == 64) ? 6 : (t.spw == 32) ? 5 : 4;
+        t.nb = b->nb;
+        t.P = b->P;
+        t.rcp_seg_len = 1.0f / (float)t.seg_len;
+        t.rcp_ph_len = 1.0f / (float)t.ph_len;
+        t.rcp_y2b = 1.0f / (float)t.y2b;
         t.n_tiles = std::max(1, (t.n_b + b->tile_b - 1) / b->tile_b);
         if (out_off + (size_t)t.n_b > out_stride && (d_iq_out || d_audio_out))
             return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride);
