@@ -1,0 +1,153 @@
+// adapter_data_cb.cpp -- drives include/sdrx_gpu_adapter.hpp exactly the way sdrx's data_cb drives
+// MSD / DS (reference src/sdrx.cpp:327-346, set-up 1680-1714) and checks every output against the
+// oracle (oracle/sdrx_oracle.h).  Test program: built and run by tests/test_gpu_adapter.py on the GPU box.
+//
+//   adapter_data_cb <taps.txt> <n_channels> <n_blocks> <serial|ds>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <latch>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/sdrx_gpu_adapter.hpp"
+#include "../../oracle/sdrx_oracle.h"
+
+using sdrxgpu::iqsample_t;
+
+#define CH_IQ_BUF_SIZE 512   // reference src/sdrx.cpp:129
+
+struct Channel {            // the hot-path members of sdrx's Channel (sdrx.cpp:207-234)
+    int ch_offset;
+    sdrxgpu::MSD msd;
+    sdrxgpu::DS *ds_ptr = nullptr;
+};
+
+static double rel_err(const float *got, const float *ref, size_t n_cplx_or_real, int width)
+{
+    double rms = 0;
+    const size_t n = n_cplx_or_real;
+    for (size_t i = 0; i < n; i++) {
+        double m2 = 0;
+        for (int k = 0; k < width; k++) m2 += (double)ref[width * i + k] * ref[width * i + k];
+        rms += m2;
+    }
+    rms = std::sqrt(rms / (n ? n : 1));
+    if (rms == 0) rms = 1;
+    double worst = 0;
+    for (size_t i = 0; i < n; i++) {
+        double d2 = 0, m2 = 0;
+        for (int k = 0; k < width; k++) {
+            const double d = (double)got[width * i + k] - ref[width * i + k];
+            d2 += d * d;
+            m2 += (double)ref[width * i + k] * ref[width * i + k];
+        }
+        const double den = std::max(std::sqrt(m2), rms);
+        worst = std::max(worst, std::sqrt(d2) / den);
+    }
+    return worst;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) return 2;
+    const int n_ch = std::atoi(argv[2]), n_blocks = std::atoi(argv[3]);
+    const bool use_threaded_ds = std::string(argv[4]) == "ds";
+
+    // stage list (what sdrx.cpp:1660-1668 builds for 10 MS/s), read from the file the test wrote
+    std::ifstream f(argv[1]);
+    int N, z, n_stages, block_len;
+    f >> N >> z >> block_len >> n_stages;
+    std::vector<sdrxgpu::MSD::Stage> stages(n_stages);
+    for (auto &s : stages) {
+        size_t nt;
+        f >> s.m >> nt;
+        s.h.resize(nt);
+        for (auto &h : s.h) {
+            std::string hex;
+            f >> hex;
+            uint32_t u = (uint32_t)std::stoul(hex, nullptr, 16);
+            std::memcpy(&h, &u, 4);
+        }
+    }
+
+    // --- set-up, as sdrx.cpp:1680-1699 ---
+    std::vector<Channel> channels(n_ch);
+    std::vector<std::vector<iqsample_t>> tables(n_ch);
+    for (int c = 0; c < n_ch; c++) {
+        Channel &ch = channels[c];
+        ch.ch_offset = c - n_ch / 2;                       // includes 0: empty translator (sdrx.cpp:1685)
+        std::vector<iqsample_t> translator;
+        if (ch.ch_offset != 0) {
+            translator.resize(N);
+            sdrxgpu_make_translator(N, z, ch.ch_offset, reinterpret_cast<sdrxgpu_iq *>(translator.data()));
+        }
+        tables[c] = translator;
+        ch.msd = sdrxgpu::MSD(translator, stages, false);
+        if (use_threaded_ds) ch.ds_ptr = new sdrxgpu::DS(ch.msd);
+    }
+
+    // oracle bank over the same channels
+    std::vector<const float *> tptr(n_ch);
+    std::vector<size_t> tlen(n_ch);
+    std::vector<uint32_t> m(n_stages), nt(n_stages);
+    std::vector<const float *> taps(n_stages);
+    for (int c = 0; c < n_ch; c++) {
+        tptr[c] = reinterpret_cast<const float *>(tables[c].data());
+        tlen[c] = tables[c].size();
+    }
+    for (int s = 0; s < n_stages; s++) {
+        m[s] = (uint32_t)stages[s].m;
+        nt[s] = (uint32_t)stages[s].h.size();
+        taps[s] = stages[s].h.data();
+    }
+    sdrx_oracle_bank *ob = sdrx_oracle_bank_create(n_ch, tptr.data(), tlen.data(), n_stages, m.data(), nt.data(), taps.data(), 0, 0);
+
+    std::vector<iqsample_t> data(block_len), chunk((size_t)n_ch * CH_IQ_BUF_SIZE), ref_iq((size_t)n_ch * CH_IQ_BUF_SIZE);
+    std::vector<float> ref_audio((size_t)n_ch * CH_IQ_BUF_SIZE);
+    double worst_iq = 0, worst_audio = 0;
+    for (int blk = 0; blk < n_blocks; blk++) {
+        sdrx_oracle_synth_iq(4242, (uint64_t)blk * block_len, block_len, 0.25f, 0, nullptr, 1, nullptr, 10000,
+                             reinterpret_cast<float *>(data.data()));
+        const unsigned data_len = (unsigned)block_len;
+
+        // --- the loop of data_cb, sdrx.cpp:327-346, verbatim in shape ---
+        iqsample_t *iq_buf_ptr = chunk.data();
+        if (use_threaded_ds) {
+            auto latch = std::make_shared<std::latch>(channels.size());
+            for (auto &ch : channels) {
+                ch.ds_ptr->addJob(data.data(), data_len, iq_buf_ptr, latch);
+                iq_buf_ptr += CH_IQ_BUF_SIZE;
+            }
+            latch->wait();
+        } else {
+            for (auto &ch : channels) {
+                ch.msd.decimate(data.data(), data_len, iq_buf_ptr);
+                iq_buf_ptr += CH_IQ_BUF_SIZE;
+            }
+        }
+
+        size_t n_out = 0;
+        sdrx_oracle_bank_process(ob, reinterpret_cast<const float *>(data.data()), block_len, reinterpret_cast<float *>(ref_iq.data()),
+                                 ref_audio.data(), CH_IQ_BUF_SIZE, &n_out, 4);
+        if (n_out != CH_IQ_BUF_SIZE) {
+            std::printf("FAIL: oracle produced %zu outputs\n", n_out);
+            return 1;
+        }
+        for (int c = 0; c < n_ch; c++) {
+            worst_iq = std::max(worst_iq, rel_err(reinterpret_cast<const float *>(chunk.data() + (size_t)c * CH_IQ_BUF_SIZE),
+                                                  reinterpret_cast<const float *>(ref_iq.data() + (size_t)c * CH_IQ_BUF_SIZE), CH_IQ_BUF_SIZE, 2));
+            worst_audio = std::max(worst_audio, rel_err(channels[c].msd.audio(), ref_audio.data() + (size_t)c * CH_IQ_BUF_SIZE, CH_IQ_BUF_SIZE, 1));
+        }
+    }
+    for (auto &ch : channels) delete ch.ds_ptr;
+    sdrx_oracle_bank_destroy(ob);
+    const bool ok = sdrxgpu::last_error().empty() && worst_iq <= 1e-5 && worst_audio <= 1e-5;
+    std::printf("%s: mode=%s channels=%d blocks=%d rel_err iq=%.3e audio=%.3e %s\n", ok ? "PASS" : "FAIL", argv[4], n_ch, n_blocks,
+                worst_iq, worst_audio, sdrxgpu::last_error().c_str());
+    channels.clear();
+    sdrxgpu::shutdown();
+    return ok ? 0 : 1;
+}

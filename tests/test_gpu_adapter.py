@@ -1,0 +1,42 @@
+"""GPU test of the C++ drop-in adapter (include/sdrx_gpu_adapter.hpp): a C++ program shaped like
+sdrx's data_cb (reference src/sdrx.cpp:327-346) drives MSD::decimate / DS::addJob through the adapter
+and compares every output with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from sdrx_amd import chains
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def adapter_bin(tmp_path_factory):
+    from oracle import ffi
+    ffi.build(ref=False)
+    out = tmp_path_factory.mktemp("cpp")
+    exe = str(out / "adapter_data_cb")
+    subprocess.check_call(["g++", "-std=c++20", "-O2", "-pthread", os.path.join(ROOT, "tests", "cpp", "adapter_data_cb.cpp"),
+                           "-o", exe, "-L" + os.path.join(ROOT, "sdrx_amd", "lib"), "-lsdrxgpu",
+                           "-L" + os.path.join(ROOT, "oracle"), "-loracle",
+                           "-Wl,-rpath," + os.path.join(ROOT, "sdrx_amd", "lib"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    ch = chains.chain("10")
+    taps = str(out / "taps.txt")
+    with open(taps, "w") as f:
+        f.write(f"{ch.N} {ch.z} {ch.block_len} {len(ch.stages)}\n")
+        for s in ch.stages:
+            f.write(f"{s.m} {len(s.h)} " + " ".join(f"{int(u):08x}" for u in s.h.view(np.uint32)) + "\n")
+    return exe, taps
+
+
+@pytest.mark.parametrize("mode", ["serial", "ds"])
+def test_data_cb_loop_through_adapter(adapter_bin, mode):
+    exe, taps = adapter_bin
+    r = subprocess.run([exe, taps, "33", "3", mode], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("PASS")
