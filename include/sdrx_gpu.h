@@ -47,6 +47,11 @@ extern "C" {
 
 /* flags */
 #define SDRXGPU_FLAG_LF_AGC_ACTIVE 0x1u  /* --lf-agc: LfAGC::activate(), sdrx.cpp:1710 */
+#define SDRXGPU_FLAG_PIPELINED     0x2u  /* throughput mode for sdrxgpu_bank_process_device only: call k launches the
+                                            mixer + stages 1-2 of block k concurrently with the remaining stages and
+                                            the AGC/demod of block k-1, and returns the outputs of block k-1 (one block
+                                            = 32 ms of latency, like one more chunk in sdrx's ring of 8, sdrx.cpp:1742);
+                                            sdrxgpu_bank_flush returns the last block.  Same outputs, bit for bit. */
 
 typedef struct sdrxgpu_bank sdrxgpu_bank;
 
@@ -140,6 +145,9 @@ int sdrxgpu_bank_process(sdrxgpu_bank *bank, const sdrxgpu_iq *iq_in, size_t in_
 int sdrxgpu_bank_process_device(sdrxgpu_bank *bank, const void *d_iq_in, size_t in_len,
                                 void *d_iq_out, void *d_audio_out, size_t out_stride,
                                 size_t *out_len);
+
+/* Pipelined banks: outputs of the block whose tail is still pending (device pointers, bank's stream). */
+int sdrxgpu_bank_flush(sdrxgpu_bank *bank, void *d_iq_out, void *d_audio_out, size_t out_stride, size_t *out_len);
 
 /* Device address where the NEXT block may be written directly, and its capacity in samples. */
 int sdrxgpu_bank_ingest_buffer(sdrxgpu_bank *bank, void **d_ptr, size_t *capacity);

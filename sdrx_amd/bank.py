@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsdrxgpu.so")
 
 K_STAGE12, K_TAIL, K_AGC, K_TOTAL = 0, 1, 2, 3
 FLAG_LF_AGC_ACTIVE = 0x1
+FLAG_PIPELINED = 0x2
 
 
 class SdrxGpuError(RuntimeError):
@@ -104,6 +105,7 @@ def load_library():
     L.sdrxgpu_bank_reset.argtypes = [vp]
     L.sdrxgpu_bank_process.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(sz)]
     L.sdrxgpu_bank_process_device.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(sz)]
+    L.sdrxgpu_bank_flush.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
     L.sdrxgpu_bank_ingest_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.sdrxgpu_bank_synchronize.argtypes = [vp]
     L.sdrxgpu_bank_get_info.argtypes = [vp, C.POINTER(BankInfo)]
@@ -117,7 +119,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "sdrxgpu_agc_params_sdrx", "sdrxgpu_make_translator", "sdrxgpu_bank_create", "sdrxgpu_bank_destroy",
-    "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_ingest_buffer",
+    "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_flush", "sdrxgpu_bank_ingest_buffer",
     "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_profile_enable",
     "sdrxgpu_bank_profile_read", "sdrxgpu_bank_profile_reset", "sdrxgpu_strerror", "sdrxgpu_last_error",
     "sdrxgpu_version",
@@ -174,7 +176,7 @@ class ChannelBank:
     """
 
     def __init__(self, translators, stages, lf_agc=False, agc=None, agc_lf=None, device=-1, stream=None,
-                 max_in_len=0, block_hint=0):
+                 max_in_len=0, block_hint=0, pipelined=False):
         L = load_library()
         self._L = L
         n_ch = len(translators)
@@ -192,7 +194,7 @@ class ChannelBank:
         d_agc, d_lf = sdrx_agc_params()
         cfg = _Cfg()
         cfg.struct_size = C.sizeof(_Cfg)
-        cfg.flags = FLAG_LF_AGC_ACTIVE if lf_agc else 0
+        cfg.flags = (FLAG_LF_AGC_ACTIVE if lf_agc else 0) | (FLAG_PIPELINED if pipelined else 0)
         cfg.n_stages = len(stages)
         cfg.stages = st
         cfg.n_channels = n_ch
@@ -266,6 +268,12 @@ class ChannelBank:
         n_out = C.c_size_t(0)
         _check(self._L.sdrxgpu_bank_process_device(self._h, d_in_ptr, in_len, d_iq_out_ptr, d_audio_out_ptr,
                                                    out_stride, C.byref(n_out)), "sdrxgpu_bank_process_device")
+        return n_out.value
+
+    def flush(self, d_iq_out_ptr, d_audio_out_ptr, out_stride):
+        """Pipelined banks: outputs of the block whose tail stages are still pending."""
+        n_out = C.c_size_t(0)
+        _check(self._L.sdrxgpu_bank_flush(self._h, d_iq_out_ptr, d_audio_out_ptr, out_stride, C.byref(n_out)), "sdrxgpu_bank_flush")
         return n_out.value
 
     def ingest_buffer(self):

@@ -183,6 +183,7 @@ struct sdrxgpu_bank {
 
     // device memory
     float2 *d_x = nullptr, *d_tables = nullptr, *d_y2 = nullptr, *d_keep = nullptr;
+    float2 *d_y2b = nullptr;                  // second stage-2 scratch (pipelined mode only)
     float2 *d_hist[2] = {nullptr, nullptr};   // stage-2 history, ping-pong between calls
     int hist_cur = 0;
     int tile_b = 64;                          // final outputs per k_tail workgroup (64: 8 workgroups per CU)
@@ -191,13 +192,24 @@ struct sdrxgpu_bank {
     float4 *d_state = nullptr;
     size_t device_bytes = 0;
 
+    // pipelined mode: stage-1/2 of block k runs on `stream2` while the tail stages + AGC of block k-1
+    // run on `stream`; the tail of the newest block waits in `pending`
+    bool pipelined = false;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    struct TailJob {
+        bool valid = false;
+        TailArgs t;
+    } pending;
+    int y2_cur = 0;
+
     // stream position
     uint64_t n_in = 0, n_out = 0;
     long long x_origin = 0;          // absolute sample index held at d_x[0] (same parity as the next call's s0)
 
     // profiling
     bool prof = false;
-    std::vector<ProfSpan> pending;
+    std::vector<ProfSpan> prof_pending;
     std::vector<hipEvent_t> pool;
     double prof_ms[4] = {0, 0, 0, 0};
     uint64_t prof_n[4] = {0, 0, 0, 0};
@@ -215,7 +227,7 @@ static void free_bank(sdrxgpu_bank *b)
 {
     if (!b) return;
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    for (ProfSpan &s : b->pending) {
+    for (ProfSpan &s : b->prof_pending) {
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);
     }
@@ -223,6 +235,13 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_x);
     (void)hipFree(b->d_tables);
     (void)hipFree(b->d_y2);
+    (void)hipFree(b->d_y2b);
+    if (b->stream2) {
+        (void)hipStreamSynchronize(b->stream2);
+        (void)hipStreamDestroy(b->stream2);
+    }
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     (void)hipFree(b->d_hist[0]);
     (void)hipFree(b->d_hist[1]);
     (void)hipFree(b->d_keep);
@@ -234,6 +253,9 @@ static void free_bank(sdrxgpu_bank *b)
 
 static int init_state(sdrxgpu_bank *b)
 {
+    if (b->stream2) HIPCHK(hipStreamSynchronize(b->stream2));
+    b->pending.valid = false;
+    b->y2_cur = 0;
     HIPCHK(hipMemsetAsync(b->d_x, 0, b->x_capacity * sizeof(float2), b->stream));
     HIPCHK(hipMemsetAsync(b->d_y2, 0, (size_t)b->n_ch * b->y2_stride * sizeof(float2), b->stream));
     HIPCHK(hipMemsetAsync(b->d_hist[0], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
@@ -301,6 +323,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     b->flags = cfg->flags;
     b->agc = cfg->agc;
     b->lf = cfg->lf_agc;
+    b->pipelined = (cfg->flags & SDRXGPU_FLAG_PIPELINED) != 0;
     b->N = N;
     b->k12 = k12;
     for (uint32_t s = 0; s < cfg->n_stages; s++) {
@@ -432,6 +455,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     if ((rc = dev_alloc(b, (void **)&b->d_x, b->x_capacity * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_tables, 2 * (size_t)b->n_ch * b->tbl_stride * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_y2, (size_t)b->n_ch * b->y2_stride * sizeof(float2))) ||
+        (b->pipelined && (rc = dev_alloc(b, (void **)&b->d_y2b, (size_t)b->n_ch * b->y2_stride * sizeof(float2)))) ||
         (rc = dev_alloc(b, (void **)&b->d_hist[0], (size_t)b->n_ch * b->y2_hist * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_hist[1], (size_t)b->n_ch * b->y2_hist * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_keep, (size_t)b->n_ch * b->keep_stride * sizeof(float2))) ||
@@ -475,6 +499,15 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
             return fail(SDRXGPU_ERR_HIP, "hipFuncSetAttribute(k_tail) failed: %s", hipGetErrorString(e));
         }
     }
+    if (b->pipelined) {
+        hipError_t e = hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "pipelined-mode stream/event creation failed: %s", hipGetErrorString(e));
+        }
+    }
     rc = init_state(b);
     if (rc) {
         free_bank(b);
@@ -503,6 +536,7 @@ extern "C" int sdrxgpu_bank_synchronize(sdrxgpu_bank *b)
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_synchronize: null bank");
     HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->stream2) HIPCHK(hipStreamSynchronize(b->stream2));
     return SDRXGPU_OK;
 }
 
@@ -560,27 +594,29 @@ struct ProfScope {
     sdrxgpu_bank *b;
     ProfSpan s{};
     bool on;
-    ProfScope(sdrxgpu_bank *bank, int kernel) : b(bank), on(bank->prof)
+    hipStream_t st;
+    ProfScope(sdrxgpu_bank *bank, int kernel, hipStream_t stream = nullptr) : b(bank), on(bank->prof), st(stream ? stream : bank->stream)
     {
         if (!on) return;
         s.kernel = kernel;
         s.a = prof_event(b);
         s.b = prof_event(b);
-        (void)hipEventRecord(s.a, b->stream);
+        (void)hipEventRecord(s.a, st);
     }
     ~ProfScope()
     {
         if (!on) return;
-        (void)hipEventRecord(s.b, b->stream);
-        b->pending.push_back(s);
+        (void)hipEventRecord(s.b, st);
+        b->prof_pending.push_back(s);
     }
 };
 
 static void prof_collect(sdrxgpu_bank *b)
 {
-    if (b->pending.empty()) return;
+    if (b->prof_pending.empty()) return;
     (void)hipStreamSynchronize(b->stream);
-    for (ProfSpan &s : b->pending) {
+    if (b->stream2) (void)hipStreamSynchronize(b->stream2);
+    for (ProfSpan &s : b->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             b->prof_ms[s.kernel] += ms;
@@ -589,7 +625,7 @@ static void prof_collect(sdrxgpu_bank *b)
         b->pool.push_back(s.a);
         b->pool.push_back(s.b);
     }
-    b->pending.clear();
+    b->prof_pending.clear();
 }
 
 extern "C" int sdrxgpu_bank_profile_enable(sdrxgpu_bank *b, int enable)
@@ -625,17 +661,17 @@ extern "C" int sdrxgpu_bank_profile_reset(sdrxgpu_bank *b)
 // ------------------------------------------------------------------------------------------
 static long long floordiv(long long a, long long b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_audio_out, size_t out_stride,
-                     size_t out_off, size_t *produced)
+// Stage-1/2 of one chunk (<= max_chunk samples, already in the input ring) on stream `st`; fills `job` with
+// everything the tail launch needs except the output pointers and the history ping-pong side.
+static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2 *y2buf, sdrxgpu_bank::TailJob *job)
 {
     const K12Entry *k = b->k12;
     const long long n0 = (long long)b->n_in, n1 = n0 + (long long)in_len;
     const long long j0 = n0 / b->MM, j1 = n1 / b->MM;
     const int n_y2_new = (int)(j1 - j0);
-    *produced = 0;
+    job->valid = false;
 
     if (n_y2_new > 0) {
-        // ---- mixer + stages 1, 2 ----
         K12Launch L;
         Stage12Args &a = L.args;
         const long long s0 = j0 * b->MM;                               // abs index of the first input of y2[j0]
@@ -644,7 +680,7 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         const long long tph_abs = ((first % b->Neff) + b->Neff) % b->Neff;  // trans_pos_ of that sample (msd.hpp:135)
         const int tcopy = (int)(tph_abs & 1);                              // odd phase: table copy shifted by one entry
         L.tables = b->d_tables + (size_t)tcopy * b->n_ch * b->tbl_stride;
-        L.y2 = b->d_y2;
+        L.y2 = y2buf;
         a.n_ch = (int)b->n_ch;
         a.tbl_stride = b->tbl_stride;
         a.N = b->Neff;
@@ -672,17 +708,15 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         L.CPW = b->CPW;
         L.grid = a.n_cgx * a.n_wt;
         {
-            ProfScope ps(b, SDRXGPU_K_STAGE12);
-            HIPCHK(k->fn(L, b->stream));
+            ProfScope ps(b, SDRXGPU_K_STAGE12, st);
+            HIPCHK(k->fn(L, st));
         }
 
-        // ---- remaining stage(s) ----
-        TailArgs t;
+        // ---- parameters of the remaining stage(s) ----
+        TailArgs &t = job->t;
         memset(&t, 0, sizeof(t));
         const int ns = (int)b->n_stages;
-        t.y2_new = b->d_y2;
-        t.hist_in = b->d_hist[b->hist_cur];
-        t.hist_out = b->d_hist[b->hist_cur ^ 1];
+        t.y2_new = y2buf;
         t.n_ch = (int)b->n_ch;
         t.y2_stride = b->y2_stride;
         t.hist = b->y2_hist;
@@ -724,63 +758,109 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
         t.rcp_ph_len = 1.0f / (float)t.ph_len;
         t.rcp_y2b = 1.0f / (float)t.y2b;
         t.n_tiles = std::max(1, (t.n_b + b->tile_b - 1) / b->tile_b);
-        if (out_off + (size_t)t.n_b > out_stride && (d_iq_out || d_audio_out))
-            return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride);
         if (t.n_b > b->keep_stride) return fail(SDRXGPU_ERR_HIP, "internal: %d outputs > keep_stride %d", t.n_b, b->keep_stride);
-        t.iq_out = d_iq_out ? d_iq_out + out_off : nullptr;
-        t.out_stride = (int)out_stride;
-        {
-            ProfScope ps(b, SDRXGPU_K_TAIL);
-            hipLaunchKernelGGL(k_tail, dim3(((b->n_ch + 7) / 8 * 8) * t.n_tiles), dim3(256), b->tail_lds, b->stream, t);
-            HIPCHK(hipGetLastError());
-        }
-        b->hist_cur ^= 1;
-
-        // ---- AGC -> |.| -> LF AGC ----
-        if (t.n_b > 0) {
-            AgcArgs g;
-            g.iq = b->d_keep;
-            g.iq_stride = b->keep_stride;
-            g.audio = d_audio_out ? d_audio_out + out_off : b->d_audio_keep;
-            g.out_stride = d_audio_out ? (int)out_stride : b->keep_stride;
-            g.state = b->d_state;
-            g.n_ch = (int)b->n_ch;
-            g.n_out = t.n_b;
-            g.lf_active = (b->flags & SDRXGPU_FLAG_LF_AGC_ACTIVE) ? 1 : 0;
-            g.audio_vec = (((uintptr_t)g.audio & 15) == 0 && (g.out_stride & 3) == 0) ? 1 : 0;
-            auto fill = [](AgcParams &p, const sdrxgpu_agc_params &s) {
-                p.attack = s.attack;
-                p.decay = s.decay;
-                p.reference = s.reference;
-                p.max_gain = s.max_gain;
-                p.min_gain = (s.max_gain > 0.0f) ? 1.0f / s.max_gain : 1.0f / 200.0f;   // agc.hpp:34, 42
-                p.alpha = s.alpha;
-            };
-            fill(g.agc, b->agc);
-            fill(g.lf, b->lf);
-            ProfScope ps(b, SDRXGPU_K_AGC);
-            hipLaunchKernelGGL(k_agc, dim3((b->n_ch + kWave - 1) / kWave), dim3(kWave), 0, b->stream, g);
-            HIPCHK(hipGetLastError());
-        }
-        *produced = (size_t)t.n_b;
-        b->n_out += (uint64_t)t.n_b;
+        job->valid = true;
     }
 
     // keep the last HIST (+1 when the next call's first body would otherwise start on an odd index)
     // input samples in front of the next block
     {
-        const long long n1b = n0 + (long long)in_len;
-        const long long s0_next = (n1b / b->MM) * b->MM;
-        long long origin_next = n1b - b->HIST;
+        const long long s0_next = (n1 / b->MM) * b->MM;
+        long long origin_next = n1 - b->HIST;
         if ((origin_next - s0_next) & 1) origin_next -= 1;
         const int src_off = (int)(origin_next - b->x_origin);
-        const int cnt = (int)(n1b - origin_next);
+        const int cnt = (int)(n1 - origin_next);
         if (src_off < 0) return fail(SDRXGPU_ERR_HIP, "internal: history roll offset %d < 0", src_off);
-        hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(256), 0, b->stream, b->d_x, src_off, cnt);
+        hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(256), 0, st, b->d_x, src_off, cnt);
         HIPCHK(hipGetLastError());
         b->x_origin = origin_next;
     }
     b->n_in += in_len;
+    return SDRXGPU_OK;
+}
+
+// Tail stage(s) + AGC/demod of a prepared job on the bank's stream, outputs to the given device pointers.
+static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq_out, float *d_audio_out, size_t out_stride,
+                       size_t out_off, size_t *produced)
+{
+    *produced = 0;
+    if (!job->valid) return SDRXGPU_OK;
+    TailArgs &t = job->t;
+    job->valid = false;
+    if (out_off + (size_t)t.n_b > out_stride && (d_iq_out || d_audio_out))
+        return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride);
+    t.hist_in = b->d_hist[b->hist_cur];
+    t.hist_out = b->d_hist[b->hist_cur ^ 1];
+    t.iq_out = d_iq_out ? d_iq_out + out_off : nullptr;
+    t.out_stride = (int)out_stride;
+    {
+        ProfScope ps(b, SDRXGPU_K_TAIL);
+        hipLaunchKernelGGL(k_tail, dim3(((b->n_ch + 7) / 8 * 8) * t.n_tiles), dim3(256), b->tail_lds, b->stream, t);
+        HIPCHK(hipGetLastError());
+    }
+    b->hist_cur ^= 1;
+
+    // ---- AGC -> |.| -> LF AGC ----
+    if (t.n_b > 0) {
+        AgcArgs g;
+        g.iq = b->d_keep;
+        g.iq_stride = b->keep_stride;
+        g.audio = d_audio_out ? d_audio_out + out_off : b->d_audio_keep;
+        g.out_stride = d_audio_out ? (int)out_stride : b->keep_stride;
+        g.state = b->d_state;
+        g.n_ch = (int)b->n_ch;
+        g.n_out = t.n_b;
+        g.lf_active = (b->flags & SDRXGPU_FLAG_LF_AGC_ACTIVE) ? 1 : 0;
+        g.audio_vec = (((uintptr_t)g.audio & 15) == 0 && (g.out_stride & 3) == 0) ? 1 : 0;
+        auto fill = [](AgcParams &p, const sdrxgpu_agc_params &s) {
+            p.attack = s.attack;
+            p.decay = s.decay;
+            p.reference = s.reference;
+            p.max_gain = s.max_gain;
+            p.min_gain = (s.max_gain > 0.0f) ? 1.0f / s.max_gain : 1.0f / 200.0f;   // agc.hpp:34, 42
+            p.alpha = s.alpha;
+        };
+        fill(g.agc, b->agc);
+        fill(g.lf, b->lf);
+        ProfScope ps(b, SDRXGPU_K_AGC);
+        hipLaunchKernelGGL(k_agc, dim3((b->n_ch + kWave - 1) / kWave), dim3(kWave), 0, b->stream, g);
+        HIPCHK(hipGetLastError());
+    }
+    *produced = (size_t)t.n_b;
+    b->n_out += (uint64_t)t.n_b;
+    return SDRXGPU_OK;
+}
+
+// one chunk through all kernels, in order, on the bank's stream
+static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_audio_out, size_t out_stride,
+                     size_t out_off, size_t *produced)
+{
+    sdrxgpu_bank::TailJob job;
+    int rc = launch_stage12(b, in_len, b->stream, b->d_y2, &job);
+    if (rc) return rc;
+    return launch_tail(b, &job, d_iq_out, d_audio_out, out_stride, out_off, produced);
+}
+
+// Pipelined mode: stage-1/2 of THIS block on stream2, concurrently the tail + AGC of the PREVIOUS block on the
+// bank's stream (they bound on different resources: packed-fp32 issue vs. HBM); the two meet again before the
+// call's work on the bank's stream is complete.  Outputs (and *produced) are those of the previous block.
+static int run_chunk_pipelined(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_audio_out, size_t out_stride,
+                               size_t *produced)
+{
+    HIPCHK(hipEventRecord(b->ev_fork, b->stream));            // input copy (and everything before) done
+    HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+    sdrxgpu_bank::TailJob job;
+    float2 *y2buf = b->y2_cur ? b->d_y2b : b->d_y2;
+    int rc = launch_stage12(b, in_len, b->stream2, y2buf, &job);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(b->ev_join, b->stream2));
+    rc = launch_tail(b, &b->pending, d_iq_out, d_audio_out, out_stride, 0, produced);
+    if (rc) return rc;
+    HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+    if (job.valid) {
+        b->pending = job;
+        b->y2_cur ^= 1;
+    }
     return SDRXGPU_OK;
 }
 
@@ -790,6 +870,8 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "process: null bank");
     if (in_len && !in) return fail(SDRXGPU_ERR_INVALID_ARG, "process: null input");
     if (b->HIST + 1 > 256) return fail(SDRXGPU_ERR_UNSUPPORTED, "internal: history %d > 255", b->HIST);
+    if (b->pipelined && (in_is_host || out_is_host || in_len > b->max_chunk))
+        return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a pipelined bank takes device pointers and at most max_in_len samples per call");
     HIPCHK(hipSetDevice(b->device));
     ProfScope total(b, SDRXGPU_K_TOTAL);
 
@@ -822,6 +904,9 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
                                             (size_t)b->keep_stride * sizeof(float), produced * sizeof(float), b->n_ch,
                                             hipMemcpyDeviceToHost, b->stream));
             }
+        } else if (b->pipelined) {
+            rc = run_chunk_pipelined(b, n, (float2 *)iq_out, (float *)audio_out, out_stride, &produced);
+            if (rc) return rc;
         } else {
             rc = run_chunk(b, n, (float2 *)iq_out, (float *)audio_out, out_stride, produced_total, &produced);
             if (rc) return rc;
@@ -844,4 +929,14 @@ extern "C" int sdrxgpu_bank_process_device(sdrxgpu_bank *b, const void *d_iq_in,
                                            void *d_audio_out, size_t out_stride, size_t *out_len)
 {
     return process_impl(b, d_iq_in, false, in_len, d_iq_out, d_audio_out, false, out_stride, out_len);
+}
+
+extern "C" int sdrxgpu_bank_flush(sdrxgpu_bank *b, void *d_iq_out, void *d_audio_out, size_t out_stride, size_t *out_len)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "flush: null bank");
+    HIPCHK(hipSetDevice(b->device));
+    size_t produced = 0;
+    int rc = launch_tail(b, &b->pending, (float2 *)d_iq_out, (float *)d_audio_out, out_stride, 0, &produced);
+    if (out_len) *out_len = produced;
+    return rc;
 }

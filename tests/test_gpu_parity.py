@@ -261,6 +261,43 @@ def test_device_pointer_entry_and_ingest_buffer():
     bank.close()
 
 
+def test_pipelined_mode_is_bit_identical_one_call_late():
+    """SDRXGPU_FLAG_PIPELINED: call k returns block k-1, flush returns the last one; same bits as the serial order."""
+    import torch
+    ch = chains.chain("10")
+    offs = list(range(-20, 21))
+    tabs = sb.translators_for(ch, offs)
+    n_ch = len(offs)
+    blocks = [synth.synth_iq(17, b * ch.block_len, ch.block_len, 0.25) for b in range(4)]
+    serial = sb.ChannelBank(tabs, ch.stage_tuples())
+    want = [serial.process(x) for x in blocks]
+    serial.close()
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), pipelined=True)
+    d_iq = torch.zeros(n_ch, 512, 2, device="cuda")
+    d_au = torch.zeros(n_ch, 512, device="cuda")
+    got = []
+    for k, x in enumerate(blocks):
+        d_x = torch.from_numpy(x.view(np.float32).copy()).cuda()
+        torch.cuda.synchronize()
+        n = bank.process_device(d_x.data_ptr(), ch.block_len, d_iq.data_ptr(), d_au.data_ptr(), 512)
+        bank.synchronize()
+        assert n == (0 if k == 0 else 512)
+        if k:
+            got.append((d_iq.cpu().numpy().reshape(n_ch, 1024).view(np.complex64).copy(), d_au.cpu().numpy().copy()))
+    assert bank.flush(d_iq.data_ptr(), d_au.data_ptr(), 512) == 512
+    bank.synchronize()
+    got.append((d_iq.cpu().numpy().reshape(n_ch, 1024).view(np.complex64).copy(), d_au.cpu().numpy().copy()))
+    assert bank.flush(d_iq.data_ptr(), d_au.data_ptr(), 512) == 0
+    for (a, b), (c, d) in zip(want, got):
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+        assert np.array_equal(b.view(np.uint32), d.view(np.uint32))
+    # host-pointer entry is refused on a pipelined bank (it promises outputs on return)
+    with pytest.raises(sb.SdrxGpuError) as e:
+        bank.process(blocks[0])
+    assert e.value.code == -5
+    bank.close()
+
+
 def test_error_behaviour():
     ch = chains.chain("10")
     tabs = sb.translators_for(ch, [5])
