@@ -47,6 +47,7 @@ extern "C" {
 
 /* flags */
 #define SDRXGPU_FLAG_LF_AGC_ACTIVE 0x1u  /* --lf-agc: LfAGC::activate(), sdrx.cpp:1710 */
+#define SDRXGPU_FLAG_FTFIR         0x4u  /* --ftfir (EXPERIMENTAL in the reference, sdrx.cpp:1199): MSD's use_ftfir, msd.hpp:104-131 */
 #define SDRXGPU_FLAG_PIPELINED     0x2u  /* throughput mode for sdrxgpu_bank_process_device only: call k launches the
                                             mixer + stages 1-2 of block k concurrently with the remaining stages and
                                             the AGC/demod of block k-1, and returns the outputs of block k-1 (one block

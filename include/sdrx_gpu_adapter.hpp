@@ -23,7 +23,7 @@
 //     must be called in lockstep, once per block each (exactly what data_cb does);
 //   * a copy of an MSD (Channel assignment, DS's internal copy) is the SAME channel, not a second
 //     delay line;
-//   * use_ftfir (EXPERIMENTAL in the reference, sdrx.cpp:1199) is not supported by the GPU path yet.
+//   * use_ftfir (EXPERIMENTAL in the reference, sdrx.cpp:1199) maps to SDRXGPU_FLAG_FTFIR.
 #ifndef SDRX_GPU_ADAPTER_HPP
 #define SDRX_GPU_ADAPTER_HPP
 
@@ -90,10 +90,6 @@ struct Group {
     {
         sealed = true;
         consumed.assign(translators.size(), 0);
-        if (use_ftfir) {
-            fail("use_ftfir is not supported by the GPU channel bank");
-            return;
-        }
         std::vector<sdrxgpu_stage> st(stages.size());
         for (size_t i = 0; i < stages.size(); i++) {
             st[i].m = (uint32_t)stages[i].m;
@@ -108,7 +104,7 @@ struct Group {
         sdrxgpu_bank_cfg cfg;
         std::memset(&cfg, 0, sizeof(cfg));
         cfg.struct_size = sizeof(cfg);
-        cfg.flags = lf_agc ? SDRXGPU_FLAG_LF_AGC_ACTIVE : 0;
+        cfg.flags = (lf_agc ? SDRXGPU_FLAG_LF_AGC_ACTIVE : 0) | (use_ftfir ? SDRXGPU_FLAG_FTFIR : 0);
         cfg.n_stages = (uint32_t)st.size();
         cfg.stages = st.data();
         cfg.n_channels = (uint32_t)ch.size();

@@ -110,7 +110,15 @@ struct K12Launch {
 
 typedef hipError_t (*k12_launch_fn)(const K12Launch &, hipStream_t);
 
-template <int M1, int T1, int M2, int T2, int Y2B>
+// FULL: every (W, CPW) geometry is compiled (the chains of BASELINE.json's configs); otherwise the four that
+// matter for large and small banks.
+static bool k12_geometry_compiled(bool full, int W, int CPW)
+{
+    if (full) return (W == 16 || W == 8 || W == 4) && (CPW == 4 || CPW == 2 || CPW == 1);
+    return (CPW == 4 && (W == 16 || W == 8 || W == 4)) || (W == 4 && CPW == 1);
+}
+
+template <int M1, int T1, int M2, int T2, int Y2B, bool FULL>
 static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
 {
     Stage12Taps<T1, T2> taps;
@@ -122,21 +130,29 @@ static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
                            L.tables, L.y2, L.args, taps);                                                       \
         return hipGetLastError();                                                                               \
     }
-    SDRX_K12_CASE(16, 4) SDRX_K12_CASE(16, 2) SDRX_K12_CASE(16, 1)
-    SDRX_K12_CASE(8, 4) SDRX_K12_CASE(8, 2) SDRX_K12_CASE(8, 1)
-    SDRX_K12_CASE(4, 4) SDRX_K12_CASE(4, 2) SDRX_K12_CASE(4, 1)
+    SDRX_K12_CASE(16, 4) SDRX_K12_CASE(8, 4) SDRX_K12_CASE(4, 4) SDRX_K12_CASE(4, 1)
+    if constexpr (FULL) {
+        SDRX_K12_CASE(16, 2) SDRX_K12_CASE(16, 1) SDRX_K12_CASE(8, 2) SDRX_K12_CASE(8, 1) SDRX_K12_CASE(4, 2)
+    }
 #undef SDRX_K12_CASE
     return hipErrorInvalidValue;
 }
 
 struct K12Entry {
     int M1, T1, M2, T2, Y2B;
+    bool full;
     k12_launch_fn fn;
 };
 
+// one entry per first-two-stages pair of the reference's chains (sdrx.cpp:1588-1668)
 static const K12Entry k12_table[] = {
-    {5, 17, 5, 19, 4, launch_k12<5, 17, 5, 19, 4>},   // 10 MS/s   (sdrx.cpp:1660-1668)
-    {2, 9, 3, 13, 4, launch_k12<2, 9, 3, 13, 4>},     // 2.4 MS/s  (sdrx.cpp:1629-1637)
+    {5, 17, 5, 19, 4, true, launch_k12<5, 17, 5, 19, 4, true>},      // 10 MS/s    (sdrx.cpp:1660-1668)
+    {2, 9, 3, 13, 4, true, launch_k12<2, 9, 3, 13, 4, true>},        // 2.4 MS/s   (sdrx.cpp:1629-1637)
+    {3, 13, 4, 25, 4, false, launch_k12<3, 13, 4, 25, 4, false>},    // 0.96 MS/s  (sdrx.cpp:1589-1596)
+    {3, 13, 5, 19, 4, false, launch_k12<3, 13, 5, 19, 4, false>},    // 1.2 MS/s   (sdrx.cpp:1597-1604)
+    {3, 13, 6, 23, 4, false, launch_k12<3, 13, 6, 23, 4, false>},    // 1.44 MS/s  (sdrx.cpp:1605-1612)
+    {4, 15, 5, 19, 4, false, launch_k12<4, 15, 5, 19, 4, false>},    // 1.6 MS/s   (sdrx.cpp:1613-1620)
+    {4, 15, 6, 23, 4, false, launch_k12<4, 15, 6, 23, 4, false>},    // 1.92 MS/s  (sdrx.cpp:1621-1628)
 };
 
 static const K12Entry *find_k12(int M1, int T1, int M2, int T2)
@@ -194,6 +210,7 @@ struct sdrxgpu_bank {
 
     // pipelined mode: stage-1/2 of block k runs on `stream2` while the tail stages + AGC of block k-1
     // run on `stream`; the tail of the newest block waits in `pending`
+    bool ftfir = false;
     bool pipelined = false;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -324,6 +341,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     b->agc = cfg->agc;
     b->lf = cfg->lf_agc;
     b->pipelined = (cfg->flags & SDRXGPU_FLAG_PIPELINED) != 0;
+    b->ftfir = (cfg->flags & SDRXGPU_FLAG_FTFIR) != 0;
     b->N = N;
     b->k12 = k12;
     for (uint32_t s = 0; s < cfg->n_stages; s++) {
@@ -387,6 +405,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         for (int W : {16, 8, 4}) {
             for (int CPW : {4, 2, 1}) {
+                if (!k12_geometry_compiled(k12->full, W, CPW)) continue;
                 const int SPW = kWave / CPW;
                 const size_t lds = 2 * (size_t)(SPW + W * CPW) * (b->SB * 8 + 16);
                 if (lds > 160 * 1024) continue;
@@ -416,9 +435,9 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         }
         if (const char *e = getenv("SDRXGPU_K12_W")) b->W = atoi(e);
         if (const char *e = getenv("SDRXGPU_K12_CPW")) b->CPW = atoi(e);
-        if (!((b->W == 16 || b->W == 8 || b->W == 4) && (b->CPW == 4 || b->CPW == 2 || b->CPW == 1))) {
+        if (!k12_geometry_compiled(k12->full, b->W, b->CPW)) {
             free_bank(b);
-            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: SDRXGPU_K12_W/CPW must be 4|8|16 and 1|2|4");
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: stage-1/2 geometry W=%d CPW=%d is not compiled for this chain", b->W, b->CPW);
         }
         if (cfg->block_hint) {
             if (b->bps % cfg->block_hint) {
@@ -478,7 +497,10 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
                 for (int i = 0; i < b->tbl_stride; i++) {
                     if (ch.n_translator) {
                         const sdrxgpu_iq &t = ch.translator[(i + copy) % b->Neff];
-                        row[i] = make_float2(t.re, t.im);
+                        // --ftfir: MSD::S builds hk = h * t * 2 (msd.hpp:215); 2*t is exact in fp32, and a channel
+                        // without translator takes the plain path un-doubled (msd.hpp:79)
+                        const float sc = b->ftfir ? 2.0f : 1.0f;
+                        row[i] = make_float2(t.re * sc, t.im * sc);
                     } else {
                         row[i] = make_float2(1.0f, 0.0f);
                     }
@@ -677,7 +699,11 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         const long long s0 = j0 * b->MM;                               // abs index of the first input of y2[j0]
         const long long first = s0 - (long long)b->WU * b->SB;         // first warm-up sample of lane 0
         L.x = b->d_x;
-        const long long tph_abs = ((first % b->Neff) + b->Neff) % b->Neff;  // trans_pos_ of that sample (msd.hpp:135)
+        // translator entry met by input sample n: t[n mod N] on the mixer path (trans_pos_, msd.hpp:134-135);
+        // with --ftfir stage 0's coefficient sets are laid out so that sample n meets t[(n - (m1-1)) mod N]
+        // (msd.hpp:201-203: the set for output 0 starts at index N-(taps-1), its newest tap is t[0] on sample m1-1)
+        const long long tshift = b->ftfir ? (long long)(k->M1 - 1) : 0;
+        const long long tph_abs = (((first - tshift) % b->Neff) + b->Neff) % b->Neff;
         const int tcopy = (int)(tph_abs & 1);                              // odd phase: table copy shifted by one entry
         L.tables = b->d_tables + (size_t)tcopy * b->n_ch * b->tbl_stride;
         L.y2 = y2buf;

@@ -49,6 +49,36 @@ def test_golden_lf_agc_active():
     assert worst_iq <= RTOL and worst_au <= RTOL
 
 
+def test_golden_ftfir():
+    """--ftfir (msd.hpp:104-131, 192-224, 341-423) against the reference's own ftfir output."""
+    worst_iq, worst_au, _ = _run_golden("g5_fs10000_ftfir", ftfir=True)
+    print(f"ftfir: iq rel {worst_iq:.3e} audio rel {worst_au:.3e}")
+    assert worst_iq <= RTOL and worst_au <= RTOL
+
+
+@pytest.mark.parametrize("name", ["g7_fs0p96", "g7_fs1p2", "g7_fs1p44", "g7_fs1p6", "g7_fs1p92"])
+def test_golden_other_sample_rate_chains(name):
+    """The 3-stage chains of sdrx.cpp:1588-1628 (z != 1, lane spacing = k*N), incl. the tuner-centre channel."""
+    worst_iq, worst_au, _ = _run_golden(name)
+    print(f"{name}: iq rel {worst_iq:.3e} audio rel {worst_au:.3e}")
+    assert worst_iq <= RTOL and worst_au <= RTOL
+
+
+def test_ftfir_on_2p4_chain_vs_oracle(oracle):
+    ch = chains.chain("2.4")
+    offs = [37, 0, -5]
+    tabs = sb.translators_for(ch, offs)
+    blocks = [synth.synth_iq(31, b * ch.block_len, ch.block_len, 0.25) for b in range(2)]
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), ftfir=True)
+    got = np.concatenate([bank.process(x)[0] for x in blocks], axis=1)
+    bank.close()
+    ref = []
+    for t in tabs:
+        m = oracle.msd(t, ch.stage_tuples(), True)
+        ref.append(np.concatenate([m.decimate(x) for x in blocks]))
+    assert rel_err_rows(got, np.stack(ref)) <= RTOL
+
+
 def test_golden_ragged_call_lengths():
     """decimate accepts any in_len and reports out_len (msd.hpp:73-75,158): 0, 1, 624, 625 ... samples."""
     worst_iq, worst_au, g = _run_golden("g6_fs10000_ragged")
