@@ -97,6 +97,13 @@ typedef struct {
                                             0 = 32 ms block of this chain's rate * 1 (longer calls
                                             are split internally)                */
     uint32_t               block_hint;   /* 0 = auto; else bodies per lane of the stage-1/2 kernel */
+    /* Optional audio band-pass on every channel's demodulated envelope: FIR::filter with setGain
+     * (src/fir.hpp:79-127; sdrx runs FIR2 with coeff_bp4am_channel, coeffs.hpp:1812, on the mixed stereo
+     * sum, sdrx.cpp:646 -- linear, so per-channel mono filtering before the mix is the same thing).
+     * n_audio_fir_taps == 0: off.  Taps are copied at create; gain in dB as FIR::setGain takes it. */
+    const float           *audio_fir_taps;
+    uint32_t               n_audio_fir_taps;
+    float                  audio_fir_gain_db;
 } sdrxgpu_bank_cfg;
 
 typedef struct {

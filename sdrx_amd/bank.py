@@ -48,7 +48,8 @@ class _Cfg(C.Structure):
                 ("n_channels", C.c_uint32), ("channels", C.POINTER(_Channel)),
                 ("agc", AgcParams), ("lf_agc", AgcParams),
                 ("device", C.c_int32), ("stream", C.c_void_p),
-                ("max_in_len", C.c_uint32), ("block_hint", C.c_uint32)]
+                ("max_in_len", C.c_uint32), ("block_hint", C.c_uint32),
+                ("audio_fir_taps", C.POINTER(C.c_float)), ("n_audio_fir_taps", C.c_uint32), ("audio_fir_gain_db", C.c_float)]
 
 
 class BankInfo(C.Structure):
@@ -177,7 +178,8 @@ class ChannelBank:
     """
 
     def __init__(self, translators, stages, lf_agc=False, agc=None, agc_lf=None, device=-1, stream=None,
-                 max_in_len=0, block_hint=0, pipelined=False, ftfir=False):
+                 max_in_len=0, block_hint=0, pipelined=False, ftfir=False,
+                 audio_fir=None, audio_fir_gain_db=0.0):
         L = load_library()
         self._L = L
         n_ch = len(translators)
@@ -206,6 +208,11 @@ class ChannelBank:
         cfg.stream = stream
         cfg.max_in_len = max_in_len
         cfg.block_hint = block_hint
+        if audio_fir is not None:
+            self._fir = np.ascontiguousarray(audio_fir, dtype=np.float32)
+            cfg.audio_fir_taps = self._fir.ctypes.data_as(C.POINTER(C.c_float))
+            cfg.n_audio_fir_taps = len(self._fir)
+            cfg.audio_fir_gain_db = audio_fir_gain_db
         h = C.c_void_p()
         _check(L.sdrxgpu_bank_create(C.byref(cfg), C.byref(h)), "sdrxgpu_bank_create")
         self._h = h

@@ -612,6 +612,39 @@ __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
     a.state[ch] = make_float4(st.g, st.pw, st.gl, st.pl);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_audio_fir: optional per-channel audio FIR (reference FIR::filter, src/fir.hpp:85-102): direct
+// form, c[0] meets the OLDEST sample of the window, products accumulated in tap order.  One
+// workgroup per channel; the channel's T-1 history samples + the block live in LDS; in place.
+// ------------------------------------------------------------------------------------------
+struct AudioFirArgs {
+    float *audio;            // [n_ch][stride], filtered in place
+    float *hist;             // [n_ch][T-1] previous inputs
+    const float *taps;       // [T] gain-adjusted (c_adj_, fir.hpp:105-115)
+    int n_ch, n_out, stride, T;
+};
+
+__global__ __launch_bounds__(256) void k_audio_fir(const AudioFirArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float *c = fsm;                       // [T]
+    float *buf = fsm + a.T;               // [T-1 + n_out]
+    const int ch = blockIdx.x;
+    const int tid = threadIdx.x;
+    float *row = a.audio + (size_t)ch * a.stride;
+    float *h = a.hist + (size_t)ch * (a.T - 1);
+    for (int i = tid; i < a.T; i += blockDim.x) c[i] = a.taps[i];
+    for (int i = tid; i < a.T - 1; i += blockDim.x) buf[i] = h[i];
+    for (int i = tid; i < a.n_out; i += blockDim.x) buf[a.T - 1 + i] = row[i];
+    __syncthreads();
+    for (int i = tid; i < a.n_out; i += blockDim.x) {
+        float acc = 0.0f;
+        for (int k = 0; k < a.T; k++) acc = fmaf(c[k], buf[i + k], acc);
+        row[i] = acc;
+    }
+    for (int i = tid; i < a.T - 1; i += blockDim.x) h[i] = buf[a.n_out + i];
+}
+
 // move x[src_off .. src_off+cnt) to x[0 .. cnt) (ranges may overlap; cnt <= 256)
 __global__ void k_roll_history(float2 *x, int src_off, int cnt)
 {

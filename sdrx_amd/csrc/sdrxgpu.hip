@@ -206,6 +206,8 @@ struct sdrxgpu_bank {
     size_t tail_lds = 0;
     float *d_audio_keep = nullptr;
     float4 *d_state = nullptr;
+    float *d_fir_taps = nullptr, *d_fir_hist = nullptr;   // optional audio FIR
+    int fir_T = 0;
     size_t device_bytes = 0;
 
     // pipelined mode: stage-1/2 of block k runs on `stream2` while the tail stages + AGC of block k-1
@@ -264,6 +266,8 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_keep);
     (void)hipFree(b->d_audio_keep);
     (void)hipFree(b->d_state);
+    (void)hipFree(b->d_fir_taps);
+    (void)hipFree(b->d_fir_hist);
     if (b->owns_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -278,6 +282,7 @@ static int init_state(sdrxgpu_bank *b)
     HIPCHK(hipMemsetAsync(b->d_hist[0], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
     HIPCHK(hipMemsetAsync(b->d_hist[1], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
     b->hist_cur = 0;
+    if (b->fir_T) HIPCHK(hipMemsetAsync(b->d_fir_hist, 0, (size_t)b->n_ch * (b->fir_T - 1) * sizeof(float), b->stream));
     std::vector<float4> st(b->n_ch, make_float4(b->agc.init_gain, b->agc.init_power, b->lf.init_gain, b->lf.init_power));
     HIPCHK(hipMemcpyAsync(b->d_state, st.data(), st.size() * sizeof(float4), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -519,6 +524,26 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "hipFuncSetAttribute(k_tail) failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (cfg->n_audio_fir_taps) {
+        if (!cfg->audio_fir_taps || cfg->n_audio_fir_taps > 4096) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: audio FIR needs 1..4096 taps");
+        }
+        b->fir_T = (int)cfg->n_audio_fir_taps;
+        std::vector<float> c(cfg->audio_fir_taps, cfg->audio_fir_taps + b->fir_T);
+        // FIR::setGain, fir.hpp:105-115: c_adj = c * pow(10.0f, gain/20.0f)   (float pow, as the reference)
+        for (float &v : c) v = v * std::pow(10.0f, cfg->audio_fir_gain_db / 20.0f);
+        if ((rc = dev_alloc(b, (void **)&b->d_fir_taps, c.size() * sizeof(float))) ||
+            (rc = dev_alloc(b, (void **)&b->d_fir_hist, (size_t)b->n_ch * (b->fir_T - 1) * sizeof(float) + 16))) {
+            free_bank(b);
+            return rc;
+        }
+        hipError_t e = hipMemcpy(b->d_fir_taps, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "audio FIR tap upload failed: %s", hipGetErrorString(e));
         }
     }
     if (b->pipelined) {
@@ -851,6 +876,19 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         ProfScope ps(b, SDRXGPU_K_AGC);
         hipLaunchKernelGGL(k_agc, dim3((b->n_ch + kWave - 1) / kWave), dim3(kWave), 0, b->stream, g);
         HIPCHK(hipGetLastError());
+        if (b->fir_T) {
+            AudioFirArgs f;
+            f.audio = g.audio;
+            f.stride = g.out_stride;
+            f.hist = b->d_fir_hist;
+            f.taps = b->d_fir_taps;
+            f.n_ch = (int)b->n_ch;
+            f.n_out = t.n_b;
+            f.T = b->fir_T;
+            const size_t lds = ((size_t)2 * b->fir_T + t.n_b) * sizeof(float);
+            hipLaunchKernelGGL(k_audio_fir, dim3(b->n_ch), dim3(256), lds, b->stream, f);
+            HIPCHK(hipGetLastError());
+        }
     }
     *produced = (size_t)t.n_b;
     b->n_out += (uint64_t)t.n_b;

@@ -49,6 +49,19 @@ def test_golden_lf_agc_active():
     assert worst_iq <= RTOL and worst_au <= RTOL
 
 
+def test_golden_audio_fir_config1():
+    """Config 1 end to end: 2.4 MS/s -> 16 kS/s audio incl. the 197-tap audio band-pass (fir.hpp:79-127)."""
+    for name, lf in (("g1_fs2400_c1", False), ("g1_fs2400_c1_lfagc", True)):
+        g = load_golden(name)
+        ch, blocks = regen_blocks(g)
+        bank = sb.ChannelBank(_tables(g, ch), ch.stage_tuples(), lf_agc=lf, audio_fir=chains.audio_bpf_taps(), audio_fir_gain_db=0.0)
+        au = np.concatenate([bank.process(x)[1] for x in blocks], axis=1)
+        bank.close()
+        e = rel_err_rows(au, g["audio_fir"])
+        print(f"{name}: FIR-filtered audio rel {e:.3e}")
+        assert e <= RTOL
+
+
 def test_golden_ftfir():
     """--ftfir (msd.hpp:104-131, 192-224, 341-423) against the reference's own ftfir output."""
     worst_iq, worst_au, _ = _run_golden("g5_fs10000_ftfir", ftfir=True)
