@@ -559,12 +559,13 @@ __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const Ag
     const float err = __fsub_rn(A.reference, st.pw);
     st.g = __fadd_rn(st.g, __fmul_rn(err > 0.0f ? A.decay : A.attack, err));
     st.g = st.g < A.min_gain ? A.min_gain : (st.g > A.max_gain ? A.max_gain : st.g);
-    // Demod::demod AM: std::abs, sdrx.cpp:178-180
-    const float s = __fsqrt_rn(nrm);
+    // Demod::demod AM: std::abs, sdrx.cpp:178-180.  v_sqrt_f32 (1 ulp) instead of the correctly rounded
+    // software sequence: this loop is a 512-step dependency chain, its latency is the kernel's run time
+    const float s = __builtin_amdgcn_sqrtf(nrm);
     // LfAGC::adjust, agc.hpp:106-131
     const float sl = __fmul_rn(s, st.gl);
     st.pl = __fadd_rn(st.pl, __fmul_rn(Lf.alpha, __fsub_rn(__fmul_rn(sl, sl), st.pl)));
-    const float errl = __fsub_rn(Lf.reference, __fsqrt_rn(st.pl));
+    const float errl = __fsub_rn(Lf.reference, __builtin_amdgcn_sqrtf(st.pl));
     st.gl = __fadd_rn(st.gl, __fmul_rn(errl > 0.0f ? Lf.decay : Lf.attack, errl));
     st.gl = st.gl < Lf.min_gain ? Lf.min_gain : (st.gl > Lf.max_gain ? Lf.max_gain : st.gl);
     return lf_active ? sl : s;
