@@ -341,6 +341,38 @@ def test_pipelined_mode_is_bit_identical_one_call_late():
     bank.close()
 
 
+def test_two_banks_two_threads_concurrently(oracle):
+    """BASELINE config 5's per-GPU share: independent IQ streams = independent banks, each driven from its own
+    host thread on its own HIP stream, at the same time; no state outside the banks."""
+    import threading
+    ch = chains.chain("10")
+    offs = list(range(-30, 30))
+    tabs = sb.translators_for(ch, offs)
+    streams = {sid: [synth.synth_iq(100 + sid, b * ch.block_len, ch.block_len, 0.25) for b in range(3)] for sid in (0, 1)}
+    results, errors = {}, []
+
+    def worker(sid):
+        try:
+            bank = sb.ChannelBank(tabs, ch.stage_tuples())
+            out = [bank.process(x) for x in streams[sid]]
+            results[sid] = (np.concatenate([o[0] for o in out], axis=1), np.concatenate([o[1] for o in out], axis=1))
+            bank.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(sid,)) for sid in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for sid in (0, 1):
+        ref_iq, ref_au = _oracle_bank(oracle, ch, tabs, streams[sid], threads=8)
+        assert rel_err_rows(results[sid][0], ref_iq) <= RTOL
+        assert rel_err_rows(results[sid][1], ref_au) <= RTOL
+    assert not np.array_equal(results[0][0], results[1][0])
+
+
 def test_error_behaviour():
     ch = chains.chain("10")
     tabs = sb.translators_for(ch, [5])
