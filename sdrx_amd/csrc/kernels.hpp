@@ -94,6 +94,32 @@ __device__ __forceinline__ v2f cmul_pk(v2f x, v2f t)
 // packed instruction reads the result of the instruction right before it (that adjacency costs a
 // wait state on gfx950); the two partial sums are added at the end.  Same products as the
 // reference's folded form (msd.hpp:309-331), summed in a different order (fp32 rounding only).
+// Five complex multiplies as one instruction group: mul0..mul4 then fma0..fma4, so no packed
+// instruction reads the result of the one right before it and only the group's end needs the wait
+// state (10 packed instructions + 1 s_nop instead of 10 + 10).
+__device__ __forceinline__ void cmul5_pk(const v2f (&x)[5], const v2f (&t)[5], v2f *out)
+{
+    v2f r0, r1, r2, r3, r4;
+    asm("v_pk_mul_f32 %0, %5, %10 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %6, %11 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %7, %12 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %3, %8, %13 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %4, %9, %14 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %5, %10, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %6, %11, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %2, %7, %12, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %3, %8, %13, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %4, %9, %14, %4 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "s_nop 0"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]));
+    out[0] = r0;
+    out[1] = r1;
+    out[2] = r2;
+    out[3] = r3;
+    out[4] = r4;
+}
+
 template <int T>
 __device__ __forceinline__ v2f folded_fir_pk(const v2f (&w)[T], const float *__restrict__ h)
 {
@@ -337,8 +363,12 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
                 v2f win[T1];
 #pragma unroll
                 for (int i = 0; i < C1; i++) win[i] = w1c[i];
+                if constexpr (M1 == 5) {
+                    cmul5_pk(fx[k & 1], ft, &win[C1]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < M1; e++) win[C1 + e] = cmul_pk(fx[k & 1][e], ft[e]);
+                    for (int e = 0; e < M1; e++) win[C1 + e] = cmul_pk(fx[k & 1][e], ft[e]);
+                }
 #pragma unroll
                 for (int e = 0; e < M1; e++) asm volatile("" : "+v"(win[C1 + e]));
                 __builtin_amdgcn_sched_barrier(0);
