@@ -373,6 +373,60 @@ def test_two_banks_two_threads_concurrently(oracle):
     assert not np.array_equal(results[0][0], results[1][0])
 
 
+def test_bank_without_any_translator(oracle):
+    """Every channel at the tuner centre: no translator table at all (msd.hpp:79-101 for the whole bank)."""
+    for rate in ("10", "1.2"):
+        ch = chains.chain(rate)
+        blocks = [synth.synth_iq(55, b * ch.block_len, ch.block_len, 0.25) for b in range(2)]
+        bank = sb.ChannelBank([None, None, None], ch.stage_tuples())
+        iq = np.concatenate([bank.process(x)[0] for x in blocks], axis=1)
+        bank.close()
+        m = oracle.msd(None, ch.stage_tuples())
+        ref = np.concatenate([m.decimate(x) for x in blocks])
+        for c in range(3):
+            assert rel_err(iq[c], ref) <= RTOL
+
+
+def test_single_channel_and_tiny_calls(oracle):
+    """One channel, calls shorter than the decimation factor, a 3-stage chain with z != 1."""
+    ch = chains.chain("1.44")
+    t = sb.make_translator(ch.N, ch.z, -11)
+    x = synth.synth_iq(77, 0, 3 * ch.m_total * 7 + 5, 0.3)
+    bank = sb.ChannelBank([t], ch.stage_tuples())
+    parts, p = [], 0
+    for n in (1, 2, 3, 50, 89, 90, 91, 1, 400, 10 ** 9):
+        n = min(n, len(x) - p)
+        parts.append(bank.process(x[p:p + n])[0])
+        p += n
+    got = np.concatenate(parts, axis=1)[0]
+    bank.close()
+    ref = oracle.msd(t, ch.stage_tuples()).decimate(x)
+    assert got.shape == ref.shape == (21,)
+    assert rel_err(got, ref) <= RTOL
+
+
+def test_lf_agc_and_custom_agc_parameters(oracle):
+    """LfAGC active + non-default AGC parameters (agc.hpp setters)."""
+    from oracle import ffi as offi
+    ch = chains.chain("2.4")
+    t = sb.make_translator(ch.N, ch.z, 37)
+    blocks = [synth.synth_iq(9, b * ch.block_len, ch.block_len, 0.25, [t], [0.4], ch.N, 2400) for b in range(3)]
+    agc, lf = sb.sdrx_agc_params()
+    agc.attack, agc.decay, agc.reference, agc.max_gain, agc.alpha = 2.0, 0.05, 0.5, 50.0, 0.02
+    lf.attack, lf.decay, lf.reference, lf.max_gain, lf.alpha = 0.5, 0.02, 0.7, 20.0, 0.01
+    bank = sb.ChannelBank([t], ch.stage_tuples(), lf_agc=True, agc=agc, agc_lf=lf)
+    au = np.concatenate([bank.process(x)[1] for x in blocks], axis=1)[0]
+    bank.close()
+    pair = oracle.agc_pair(True)
+    for name, src in (("agc", agc), ("lf", lf)):
+        dst = getattr(pair, name)
+        dst.attack, dst.decay, dst.reference, dst.alpha = src.attack, src.decay, src.reference, src.alpha
+        dst.max_gain, dst.min_gain = src.max_gain, 1.0 / src.max_gain
+    m = oracle.msd(t, ch.stage_tuples())
+    ref = np.concatenate([pair.adjust_lf(oracle.demod_am(pair.adjust(m.decimate(x)))) for x in blocks])
+    assert rel_err(au, ref) <= RTOL
+
+
 def test_error_behaviour():
     ch = chains.chain("10")
     tabs = sb.translators_for(ch, [5])
