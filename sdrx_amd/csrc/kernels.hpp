@@ -193,19 +193,25 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 template <int SB>
 __device__ __forceinline__ void dma_row(const float2 *src_row /* wave-uniform */, char *lds_row /* wave-uniform */, int lane)
 {
-    static_assert(SB / 2 <= kWave, "row longer than one DMA instruction (64 x 16 B)");
-    if (lane < SB / 2) {
-        // uniform 64-bit base + 32-bit per-lane byte offset -> the saddr + voffset form of the
-        // instruction (no 64-bit per-lane address registers).  generic -> global / LDS address spaces:
-        // a global generic pointer is its own global address; the low 32 bits of a generic LDS pointer
-        // are the LDS offset.
-        const char *g = reinterpret_cast<const char *>(src_row) + (uint32_t)(lane * 16);
-        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)g, (lds_void *)(uint32_t)(uintptr_t)lds_row, 16, 0, 0);
+    // a row of SB samples = SB/2 16-byte pieces, 64 per instruction
+    constexpr int PIECES = (SB / 2 + kWave - 1) / kWave;
+#pragma unroll
+    for (int pc = 0; pc < PIECES; pc++) {
+        if (pc * kWave + lane < SB / 2) {
+            // uniform 64-bit base + 32-bit per-lane byte offset -> the saddr + voffset form of the
+            // instruction (no 64-bit per-lane address registers).  generic -> global / LDS address spaces:
+            // a global generic pointer is its own global address; the low 32 bits of a generic LDS pointer
+            // are the LDS offset.
+            const char *g = reinterpret_cast<const char *>(src_row) + (uint32_t)((pc * kWave + lane) * 16);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)g, (lds_void *)(uint32_t)(uintptr_t)(lds_row + pc * kWave * 16), 16, 0, 0);
+        }
     }
 }
 
+// First stages with a large decimation factor (6 MS/s: m=15/53 taps, 2.56 MS/s: m=20/51 taps) keep more
+// than 128 registers live; they run at a lower occupancy and without the double-buffered LDS reads.
 template <int M1, int T1, int M2, int T2, int Y2B, int W, int CPW>
-__global__ __launch_bounds__(kWave * W, 4)
+__global__ __launch_bounds__(kWave * W, (M1 > 6 ? 1 : 4))
 void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
                const Stage12Args a, const Stage12Taps<T1, T2> taps)
 {
@@ -342,7 +348,8 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
         };
 
         v2f cx = {0.f, 0.f}, ct = {0.f, 0.f};
-        v2f fx[2][M1];                 // input samples: region k+1 is fetched while region k is computed
+        constexpr bool PREFETCH = (M1 <= 6);
+        v2f fx[PREFETCH ? 2 : 1][M1];  // input samples: region k+1 is fetched while region k is computed
         v2f ft[M1];                    // translator entries (broadcast reads): fetched one region ahead too,
                                        // but consumed first, so one buffer is enough
         load_region(xrow, 0, fx[0], cx);
@@ -367,13 +374,13 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
                     cmul5_pk(fx[k & 1], ft, &win[C1]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < M1; e++) win[C1 + e] = cmul_pk(fx[k & 1][e], ft[e]);
+                    for (int e = 0; e < M1; e++) win[C1 + e] = cmul_pk(fx[PREFETCH ? (k & 1) : 0][e], ft[e]);
                 }
 #pragma unroll
                 for (int e = 0; e < M1; e++) asm volatile("" : "+v"(win[C1 + e]));
                 __builtin_amdgcn_sched_barrier(0);
                 if (k + 1 < NY1) {
-                    load_region(xrow, k + 1, fx[(k + 1) & 1], cx);
+                    load_region(xrow, k + 1, fx[PREFETCH ? ((k + 1) & 1) : 0], cx);
                     load_region(trow, k + 1, ft, ct);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -676,7 +683,7 @@ __global__ __launch_bounds__(256) void k_audio_fir(const AudioFirArgs a)
     for (int i = tid; i < a.T - 1; i += blockDim.x) h[i] = buf[a.n_out + i];
 }
 
-// move x[src_off .. src_off+cnt) to x[0 .. cnt) (ranges may overlap; cnt <= 256)
+// move x[src_off .. src_off+cnt) to x[0 .. cnt) (ranges may overlap; cnt <= blockDim.x = 1024)
 __global__ void k_roll_history(float2 *x, int src_off, int cnt)
 {
     const int i = threadIdx.x;

@@ -110,15 +110,16 @@ struct K12Launch {
 
 typedef hipError_t (*k12_launch_fn)(const K12Launch &, hipStream_t);
 
-// FULL: every (W, CPW) geometry is compiled (the chains of BASELINE.json's configs); otherwise the four that
-// matter for large and small banks.
-static bool k12_geometry_compiled(bool full, int W, int CPW)
+// level 0: every (W, CPW) geometry is compiled (the chains of BASELINE.json's configs); level 1: the four that
+// matter for large and small banks; level 2 (big first-stage decimation, register-heavy): W = 4 only.
+static bool k12_geometry_compiled(int level, int W, int CPW)
 {
-    if (full) return (W == 16 || W == 8 || W == 4) && (CPW == 4 || CPW == 2 || CPW == 1);
-    return (CPW == 4 && (W == 16 || W == 8 || W == 4)) || (W == 4 && CPW == 1);
+    if (level == 0) return (W == 16 || W == 8 || W == 4) && (CPW == 4 || CPW == 2 || CPW == 1);
+    if (level == 1) return (CPW == 4 && (W == 16 || W == 8 || W == 4)) || (W == 4 && CPW == 1);
+    return W == 4 && CPW == 4;      // (4 waves x 4 channels: the only geometry whose two tile buffers fit 160 KB of LDS)
 }
 
-template <int M1, int T1, int M2, int T2, int Y2B, bool FULL>
+template <int M1, int T1, int M2, int T2, int Y2B, int LEVEL>
 static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
 {
     Stage12Taps<T1, T2> taps;
@@ -130,8 +131,11 @@ static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
                            L.tables, L.y2, L.args, taps);                                                       \
         return hipGetLastError();                                                                               \
     }
-    SDRX_K12_CASE(16, 4) SDRX_K12_CASE(8, 4) SDRX_K12_CASE(4, 4) SDRX_K12_CASE(4, 1)
-    if constexpr (FULL) {
+    SDRX_K12_CASE(4, 4)
+    if constexpr (LEVEL <= 1) {
+        SDRX_K12_CASE(16, 4) SDRX_K12_CASE(8, 4) SDRX_K12_CASE(4, 1)
+    }
+    if constexpr (LEVEL == 0) {
         SDRX_K12_CASE(16, 2) SDRX_K12_CASE(16, 1) SDRX_K12_CASE(8, 2) SDRX_K12_CASE(8, 1) SDRX_K12_CASE(4, 2)
     }
 #undef SDRX_K12_CASE
@@ -140,19 +144,21 @@ static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
 
 struct K12Entry {
     int M1, T1, M2, T2, Y2B;
-    bool full;
+    int level;
     k12_launch_fn fn;
 };
 
 // one entry per first-two-stages pair of the reference's chains (sdrx.cpp:1588-1668)
 static const K12Entry k12_table[] = {
-    {5, 17, 5, 19, 4, true, launch_k12<5, 17, 5, 19, 4, true>},      // 10 MS/s    (sdrx.cpp:1660-1668)
-    {2, 9, 3, 13, 4, true, launch_k12<2, 9, 3, 13, 4, true>},        // 2.4 MS/s   (sdrx.cpp:1629-1637)
-    {3, 13, 4, 25, 4, false, launch_k12<3, 13, 4, 25, 4, false>},    // 0.96 MS/s  (sdrx.cpp:1589-1596)
-    {3, 13, 5, 19, 4, false, launch_k12<3, 13, 5, 19, 4, false>},    // 1.2 MS/s   (sdrx.cpp:1597-1604)
-    {3, 13, 6, 23, 4, false, launch_k12<3, 13, 6, 23, 4, false>},    // 1.44 MS/s  (sdrx.cpp:1605-1612)
-    {4, 15, 5, 19, 4, false, launch_k12<4, 15, 5, 19, 4, false>},    // 1.6 MS/s   (sdrx.cpp:1613-1620)
-    {4, 15, 6, 23, 4, false, launch_k12<4, 15, 6, 23, 4, false>},    // 1.92 MS/s  (sdrx.cpp:1621-1628)
+    {5, 17, 5, 19, 4, 0, launch_k12<5, 17, 5, 19, 4, 0>},      // 10 MS/s    (sdrx.cpp:1660-1668)
+    {2, 9, 3, 13, 4, 0, launch_k12<2, 9, 3, 13, 4, 0>},        // 2.4 MS/s   (sdrx.cpp:1629-1637)
+    {3, 13, 4, 25, 4, 1, launch_k12<3, 13, 4, 25, 4, 1>},      // 0.96 MS/s  (sdrx.cpp:1589-1596)
+    {3, 13, 5, 19, 4, 1, launch_k12<3, 13, 5, 19, 4, 1>},      // 1.2 MS/s   (sdrx.cpp:1597-1604)
+    {3, 13, 6, 23, 4, 1, launch_k12<3, 13, 6, 23, 4, 1>},      // 1.44 MS/s  (sdrx.cpp:1605-1612)
+    {4, 15, 5, 19, 4, 1, launch_k12<4, 15, 5, 19, 4, 1>},      // 1.6 MS/s   (sdrx.cpp:1613-1620)
+    {4, 15, 6, 23, 4, 1, launch_k12<4, 15, 6, 23, 4, 1>},      // 1.92 MS/s  (sdrx.cpp:1621-1628)
+    {15, 53, 5, 21, 2, 2, launch_k12<15, 53, 5, 21, 2, 2>},    // 6 MS/s     (sdrx.cpp:1651-1658)
+    {20, 51, 4, 33, 2, 2, launch_k12<20, 51, 4, 33, 2, 2>},    // 2.56 MS/s  (sdrx.cpp:1641-1648; N % m != 0, sdrx.cpp:1642)
 };
 
 static const K12Entry *find_k12(int M1, int T1, int M2, int T2)
@@ -410,11 +416,12 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         for (int W : {16, 8, 4}) {
             for (int CPW : {4, 2, 1}) {
-                if (!k12_geometry_compiled(k12->full, W, CPW)) continue;
+                if (!k12_geometry_compiled(k12->level, W, CPW)) continue;
                 const int SPW = kWave / CPW;
                 const size_t lds = 2 * (size_t)(SPW + W * CPW) * (b->SB * 8 + 16);
                 if (lds > 160 * 1024) continue;
-                int wg_per_cu = (int)std::min<size_t>(160 * 1024 / lds, (size_t)(16 / W));   // <= 4 waves/SIMD (128 VGPRs)
+                const int max_waves_cu = (k12->level == 2) ? 8 : 16;                               // register budget
+                int wg_per_cu = (int)std::min<size_t>(160 * 1024 / lds, (size_t)(max_waves_cu / W));
                 if (wg_per_cu < 1) continue;
                 const double waves_per_simd = wg_per_cu * W / 4.0;
                 const double feed = std::min(1.0, 0.35 + 0.325 * waves_per_simd);          // 1 wave/SIMD ~ 2/3 of peak issue
@@ -440,7 +447,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         }
         if (const char *e = getenv("SDRXGPU_K12_W")) b->W = atoi(e);
         if (const char *e = getenv("SDRXGPU_K12_CPW")) b->CPW = atoi(e);
-        if (!k12_geometry_compiled(k12->full, b->W, b->CPW)) {
+        if (!k12_geometry_compiled(k12->level, b->W, b->CPW)) {
             free_bank(b);
             return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: stage-1/2 geometry W=%d CPW=%d is not compiled for this chain", b->W, b->CPW);
         }
@@ -822,7 +829,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         const int src_off = (int)(origin_next - b->x_origin);
         const int cnt = (int)(n1 - origin_next);
         if (src_off < 0) return fail(SDRXGPU_ERR_HIP, "internal: history roll offset %d < 0", src_off);
-        hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(256), 0, st, b->d_x, src_off, cnt);
+        hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(1024), 0, st, b->d_x, src_off, cnt);
         HIPCHK(hipGetLastError());
         b->x_origin = origin_next;
     }
@@ -933,7 +940,7 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "process: null bank");
     if (in_len && !in) return fail(SDRXGPU_ERR_INVALID_ARG, "process: null input");
-    if (b->HIST + 1 > 256) return fail(SDRXGPU_ERR_UNSUPPORTED, "internal: history %d > 255", b->HIST);
+    if (b->HIST + 1 > 1024) return fail(SDRXGPU_ERR_UNSUPPORTED, "internal: history %d > 1023", b->HIST);
     if (b->pipelined && (in_is_host || out_is_host || in_len > b->max_chunk))
         return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a pipelined bank takes device pointers and at most max_in_len samples per call");
     HIPCHK(hipSetDevice(b->device));

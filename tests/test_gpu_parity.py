@@ -69,7 +69,7 @@ def test_golden_ftfir():
     assert worst_iq <= RTOL and worst_au <= RTOL
 
 
-@pytest.mark.parametrize("name", ["g7_fs0p96", "g7_fs1p2", "g7_fs1p44", "g7_fs1p6", "g7_fs1p92"])
+@pytest.mark.parametrize("name", ["g7_fs0p96", "g7_fs1p2", "g7_fs1p44", "g7_fs1p6", "g7_fs1p92", "g7_fs6", "g7_fs2p56"])
 def test_golden_other_sample_rate_chains(name):
     """The 3-stage chains of sdrx.cpp:1588-1628 (z != 1, lane spacing = k*N), incl. the tuner-centre channel."""
     worst_iq, worst_au, _ = _run_golden(name)

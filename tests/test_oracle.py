@@ -39,7 +39,7 @@ def _run_chain(lib, ch, table, blocks, use_ftfir=False, lf_agc=False, fir_taps=N
 
 
 def test_fixture_inventory():
-    assert len(ALL_CASES) >= 15
+    assert len(ALL_CASES) >= 16
     for must in ("g1_fs2400_c1", "g2_fs10000", "g3_fs10000_noise", "g4_fs10000_impulse", "g5_fs10000_ftfir",
                  "g6_fs10000_ragged"):
         assert must in ALL_CASES
