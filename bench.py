@@ -30,6 +30,7 @@ from sdrx_amd import bank as sb  # noqa: E402
 from sdrx_amd import chains, synth  # noqa: E402
 from sdrx_amd import dist as sdist  # noqa: E402
 
+FORCE_DIST = os.environ.get("SDRX_BENCH_FORCE_DIST") == "1"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -89,14 +90,14 @@ def time_bank(bank, fan, ring, rank, world, dist, L, d_iq, d_au, steps, warmup, 
     """W untimed warm-up steps, then exactly `steps` timed steps bracketed by synchronize + barrier."""
     def step(i):
         src = ring[i % n_ring] if rank == 0 else None
-        cur = fan.step(src)                   # N > 1: RCCL broadcast over xGMI of the shared IQ block
+        cur = fan.step(src, force=FORCE_DIST)  # N > 1: RCCL broadcast over xGMI of the shared IQ block
         n = bank.process_device(cur.data_ptr(), L, d_iq.data_ptr(), d_au.data_ptr(), 512)
         assert n == 512 or (i == 0 and n == 0)      # a pipelined bank returns block k-1 at call k
 
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     bank.profile_reset()
     bank.profile_enable(True)
@@ -105,7 +106,7 @@ def time_bank(bank, fan, ring, rank, world, dist, L, d_iq, d_au, steps, warmup, 
     for i in range(steps):
         step(warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     dt = sdist.max_over_ranks(dist, dt, device="cuda")
@@ -152,8 +153,14 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("SDRX_BENCH_FORCE_DIST") == "1"     # rehearse the RCCL path with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if force_dist and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ch = chains.chain(args.rate)
@@ -283,7 +290,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

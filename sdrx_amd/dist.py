@@ -43,9 +43,10 @@ class BlockFanout:
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
 
-    def step(self, block=None):
-        """On rank ``src`` pass the block (same shape/dtype as ``buf``); returns the buffer holding it."""
-        if self.world == 1:
+    def step(self, block=None, force=False):
+        """On rank ``src`` pass the block (same shape/dtype as ``buf``); returns the buffer holding it.
+        ``force``: run the broadcast even with a single rank (rehearsal of the RCCL path on one GPU)."""
+        if self.world == 1 and not (force and self.dist is not None):
             return block
         if self.rank == self.src:
             self.buf.copy_(block)
