@@ -245,6 +245,34 @@ def main():
         for bk in banks:
             bk.close()
 
+    host_path = None
+    if world == 1 and not args.no_extra_configs:
+        # the drop-in entry (host pointers in and out, outputs complete on return): PCIe-inclusive, NOT `value`
+        tabs = sb.translators_for(ch, offs)
+        hb = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank)
+        x_host = synth.synth_iq(9, 0, L, 0.25)
+        o_iq = np.zeros((n_ch, 512), dtype=np.complex64)
+        o_au = np.zeros((n_ch, 512), dtype=np.float32)
+        res = {}
+        for label, pin in (("pageable", False), ("page_locked", True)):
+            if pin:
+                for a_ in (x_host, o_iq, o_au):
+                    sb.host_register(a_)
+            for _ in range(2):
+                hb.process(x_host, iq_out=o_iq, audio_out=o_au)
+            n_it = 8
+            t0 = time.perf_counter()
+            for _ in range(n_it):
+                hb.process(x_host, iq_out=o_iq, audio_out=o_au)
+            dth = (time.perf_counter() - t0) / n_it
+            res[label] = {"ms_per_block": dth * 1e3, "value": n_ch * L / dth / 1e6}
+            if pin:
+                for a_ in (x_host, o_iq, o_au):
+                    sb.host_unregister(a_)
+        hb.close()
+        host_path = {"what": f"sdrxgpu_bank_process: {L * 8 / 1e6:.2f} MB H2D + {n_ch * 512 * 12 / 1e6:.1f} MB D2H per block, synchronous",
+                     "unit": "Mch-samples/s", **res}
+
     if rank == 0:
         total_cs = float(n_ch) * world * L * args.steps
         value = total_cs / dt / 1e6
@@ -285,6 +313,8 @@ def main():
         }
         if extra:
             out["other_configs"] = extra
+        if host_path:
+            out["host_pointer_entry"] = host_path
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ch, args.cpu_seconds)
         else:

@@ -160,6 +160,12 @@ int sdrxgpu_bank_flush(sdrxgpu_bank *bank, void *d_iq_out, void *d_audio_out, si
 /* Device address where the NEXT block may be written directly, and its capacity in samples. */
 int sdrxgpu_bank_ingest_buffer(sdrxgpu_bank *bank, void **d_ptr, size_t *capacity);
 
+/* Page-lock caller memory that is handed to sdrxgpu_bank_process again and again (the IQ double buffer of the
+ * device layer, the chunks of the CRB ring, reference src/crb.hpp:56): H2D/D2H then go by DMA straight from/to
+ * it instead of through the runtime's staging buffer.  Thin wrappers so that the caller needs no HIP headers. */
+int sdrxgpu_host_register(void *ptr, size_t bytes);
+int sdrxgpu_host_unregister(void *ptr);
+
 int sdrxgpu_bank_synchronize(sdrxgpu_bank *bank);
 int sdrxgpu_bank_get_info(sdrxgpu_bank *bank, sdrxgpu_bank_info *info);
 

@@ -109,6 +109,8 @@ def load_library():
     L.sdrxgpu_bank_process_device.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(sz)]
     L.sdrxgpu_bank_flush.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
     L.sdrxgpu_bank_ingest_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.sdrxgpu_host_register.argtypes = [vp, sz]
+    L.sdrxgpu_host_unregister.argtypes = [vp]
     L.sdrxgpu_bank_synchronize.argtypes = [vp]
     L.sdrxgpu_bank_get_info.argtypes = [vp, C.POINTER(BankInfo)]
     L.sdrxgpu_bank_get_gains.argtypes = [vp, vp, vp]
@@ -122,7 +124,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "sdrxgpu_agc_params_sdrx", "sdrxgpu_make_translator", "sdrxgpu_bank_create", "sdrxgpu_bank_destroy",
     "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_flush", "sdrxgpu_bank_ingest_buffer",
-    "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_profile_enable",
+    "sdrxgpu_host_register", "sdrxgpu_host_unregister", "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_profile_enable",
     "sdrxgpu_bank_profile_read", "sdrxgpu_bank_profile_reset", "sdrxgpu_strerror", "sdrxgpu_last_error",
     "sdrxgpu_version",
 ]
@@ -140,6 +142,15 @@ def _check(rc, what):
     if rc != 0:
         L = load_library()
         raise SdrxGpuError(rc, what, f"{L.sdrxgpu_strerror(rc).decode()}: {L.sdrxgpu_last_error().decode()}")
+
+
+def host_register(arr: np.ndarray):
+    """Page-lock a numpy array that is passed to ``ChannelBank.process`` repeatedly (DMA instead of staged copies)."""
+    _check(load_library().sdrxgpu_host_register(arr.ctypes.data, arr.nbytes), "sdrxgpu_host_register")
+
+
+def host_unregister(arr: np.ndarray):
+    _check(load_library().sdrxgpu_host_unregister(arr.ctypes.data), "sdrxgpu_host_unregister")
 
 
 def make_translator(N: int, z: int, ch_offset: int) -> np.ndarray:
@@ -257,12 +268,18 @@ class ChannelBank:
         return a, b
 
     # ---- the hot path ----
-    def process(self, iq, out_stride=None, want_iq=True, want_audio=True):
-        """Host buffers in, host buffers out (the drop-in call).  Returns (iq[ch, n_out], audio[ch, n_out])."""
+    def process(self, iq, out_stride=None, want_iq=True, want_audio=True, iq_out=None, audio_out=None):
+        """Host buffers in, host buffers out (the drop-in call).  Returns (iq[ch, n_out], audio[ch, n_out]).
+        ``iq_out`` / ``audio_out``: caller-owned [n_ch, out_stride] arrays to fill (e.g. page-locked ring chunks)."""
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
         stride = int(out_stride or (iq.shape[0] // self.m + 1))
-        iq_out = np.zeros((self.n_channels, stride), dtype=np.complex64) if want_iq else None
-        audio = np.zeros((self.n_channels, stride), dtype=np.float32) if want_audio else None
+        if iq_out is not None or audio_out is not None:
+            stride = (iq_out if iq_out is not None else audio_out).shape[1]
+            want_iq, want_audio = iq_out is not None, audio_out is not None
+            audio = audio_out
+        else:
+            iq_out = np.zeros((self.n_channels, stride), dtype=np.complex64) if want_iq else None
+            audio = np.zeros((self.n_channels, stride), dtype=np.float32) if want_audio else None
         n_out = C.c_size_t(0)
         _check(self._L.sdrxgpu_bank_process(self._h, iq.ctypes.data, iq.shape[0],
                                             iq_out.ctypes.data if want_iq else None,

@@ -1011,3 +1011,17 @@ extern "C" int sdrxgpu_bank_flush(sdrxgpu_bank *b, void *d_iq_out, void *d_audio
     if (out_len) *out_len = produced;
     return rc;
 }
+
+extern "C" int sdrxgpu_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(SDRXGPU_ERR_INVALID_ARG, "host_register: null/empty range");
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_host_unregister(void *ptr)
+{
+    if (!ptr) return fail(SDRXGPU_ERR_INVALID_ARG, "host_unregister: null pointer");
+    HIPCHK(hipHostUnregister(ptr));
+    return SDRXGPU_OK;
+}
