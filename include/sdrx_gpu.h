@@ -104,6 +104,17 @@ typedef struct {
     const float           *audio_fir_taps;
     uint32_t               n_audio_fir_taps;
     float                  audio_fir_gain_db;
+    /* Optional squelch, reference src/sdrx.cpp:533-573 + the gating of the audio by it, sdrx.cpp:458-503.
+     * sql_level == NULL: off (audio as if the squelch were open, the default of this library).  Otherwise one
+     * level in dB per channel (Channel::sql_level, 0 = always open); every sdrxgpu_bank_process* call must then
+     * produce exactly 512 outputs per channel (FFT_SIZE = CH_IQ_BUF_SIZE, sdrx.cpp:129-130).  Per chunk: the
+     * audio is gated by the state the PREVIOUS chunk left (ramp_up on the chunk after opening, ramp_down on the
+     * chunk after closing, silence and a frozen LF-AGC while closed), then the state is updated from this
+     * chunk's pre-AGC IQ.  Tables are the caller's (coeffs.hpp:2018/2541/3064), 512 floats each, copied. */
+    const float           *sql_level;
+    const float           *passband_shape;
+    const float           *ramp_up;
+    const float           *ramp_down;
 } sdrxgpu_bank_cfg;
 
 typedef struct {
@@ -168,6 +179,10 @@ int sdrxgpu_host_unregister(void *ptr);
 
 int sdrxgpu_bank_synchronize(sdrxgpu_bank *bank);
 int sdrxgpu_bank_get_info(sdrxgpu_bank *bank, sdrxgpu_bank_info *info);
+
+/* Squelch SNR (dB) and state (0 closed / 1 open) per channel after the last chunk (what sdrx prints,
+ * sdrx.cpp:593-634); either may be NULL. */
+int sdrxgpu_bank_get_squelch(sdrxgpu_bank *bank, float *snr_db, unsigned char *state);
 
 /* AGC gains per channel (what sdrx prints with -v, sdrx.cpp:593-634); either may be NULL. */
 int sdrxgpu_bank_get_gains(sdrxgpu_bank *bank, float *agc_gain, float *lf_agc_gain);

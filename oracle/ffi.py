@@ -259,6 +259,38 @@ class _Bank:
             self.h = None
 
 
+class _ChannelStruct(C.Structure):
+    _fields_ = [("agc", _AGCStruct), ("agc_lf", _AGCStruct), ("sql_level", C.c_float),
+                ("sql_state", C.c_int), ("sql_state_prev", C.c_int), ("snr", C.c_float)]
+
+
+class SquelchChannel:
+    """One channel of alsa_write_cb (sdrx.cpp:455-573): squelch-gated audio + squelch update per 512-sample chunk."""
+
+    def __init__(self, lib, sql_level, window, passband_shape, ramp_up, ramp_down, use_lf_agc=False):
+        assert lib.prefix == "sdrx_oracle"
+        self.L = lib.lib
+        self.c = _ChannelStruct()
+        self.L.sdrx_oracle_channel_init.argtypes = [C.POINTER(_ChannelStruct), C.c_float, C.c_int]
+        self.L.sdrx_oracle_channel_chunk.argtypes = [C.POINTER(_ChannelStruct), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
+        self.L.sdrx_oracle_channel_init(C.byref(self.c), sql_level, int(use_lf_agc))
+        self.tabs = [np.ascontiguousarray(t, dtype=np.float32) for t in (window, passband_shape, ramp_up, ramp_down)]
+
+    def chunk(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        assert iq.shape[0] == 512
+        audio = np.empty(512, dtype=np.float32)
+        self.L.sdrx_oracle_channel_chunk(C.byref(self.c), _fp(iq.view(np.float32)), *[_fp(t) for t in self.tabs], _fp(audio))
+        return audio, float(self.c.snr), int(self.c.sql_state)
+
+
+def hamming_window(lib):
+    w = np.empty(512, dtype=np.float32)
+    lib.lib.sdrx_oracle_hamming_window.argtypes = [_f32p]
+    lib.lib.sdrx_oracle_hamming_window(_fp(w))
+    return w
+
+
 _cache = {}
 
 

@@ -537,6 +537,97 @@ void sdrx_oracle_bank_destroy(sdrx_oracle_bank *b)
 }
 
 /* ------------------------------------------------------------------------- */
+/* Squelch and squelch-gated audio, one channel, one 512-sample chunk.         */
+/* ------------------------------------------------------------------------- */
+void sdrx_oracle_hamming_window(float *w)                       /* sdrx.cpp:896-900 */
+{
+    for (unsigned n = 0; n < SDRX_ORACLE_FFT_SIZE; n++)
+        w[n] = 0.54f - 0.46f * cos((2.0f * M_PI * n) / SDRX_ORACLE_FFT_SIZE);
+}
+
+void sdrx_oracle_channel_init(sdrx_oracle_channel *c, float sql_level, int use_lf_agc)
+{
+    sdrx_oracle_agc_init_sdrx(&c->agc, &c->agc_lf, use_lf_agc);
+    c->sql_level = sql_level;
+    c->sql_state = 0;              /* Channel ctor, sdrx.cpp:210 */
+    c->sql_state_prev = 0;
+    c->snr = 0.0f;
+}
+
+/* sdrx.cpp:533 (fft_in = iq * window), 538 (forward DFT, FFTW_FORWARD = exp(-j...)), 541-567 */
+float sdrx_oracle_squelch_snr(const float *iq, const float *window, const float *pb)
+{
+    enum { N = SDRX_ORACLE_FFT_SIZE };
+    static double tw_re[N], tw_im[N];
+    static int tw_ready = 0;
+    if (!tw_ready) {
+        for (int k = 0; k < N; k++) {
+            tw_re[k] = cos(-2.0 * M_PI * k / N);
+            tw_im[k] = sin(-2.0 * M_PI * k / N);
+        }
+        tw_ready = 1;
+    }
+    float in_re[N], in_im[N], out_re[N], out_im[N];
+    for (int i = 0; i < N; i++) {              /* complex<float> * float */
+        in_re[i] = iq[2 * i] * window[i];
+        in_im[i] = iq[2 * i + 1] * window[i];
+    }
+    for (int k = 0; k < N; k++) {
+        double sr = 0.0, si = 0.0;
+        for (int n = 0; n < N; n++) {
+            const int idx = (int)(((long)k * n) % N);
+            sr += in_re[n] * tw_re[idx] - in_im[n] * tw_im[idx];
+            si += in_re[n] * tw_im[idx] + in_im[n] * tw_re[idx];
+        }
+        out_re[k] = (float)sr;                 /* FFTW3f hands back floats */
+        out_im[k] = (float)si;
+    }
+    float sig_level = 0.0f;                    /* sdrx.cpp:542-550 */
+    for (unsigned i = 3; i < 91; i++) {
+        sig_level += out_re[i] * out_re[i] + out_im[i] * out_im[i];
+        sig_level += out_re[N - i] * out_re[N - i] + out_im[N - i] * out_im[N - i];
+    }
+    sig_level /= 176;
+    float ref_hi = 0.0f, ref_lo = 0.0f;        /* sdrx.cpp:552-563: norm(fft_out * passband_shape) */
+    for (unsigned i = 112; i < 157; i++) {
+        float ar = out_re[i] * pb[i], ai = out_im[i] * pb[i];
+        ref_hi += ar * ar + ai * ai;
+        float br = out_re[N - i] * pb[N - i], bi = out_im[N - i] * pb[N - i];
+        ref_lo += br * br + bi * bi;
+    }
+    ref_hi /= 45;
+    ref_lo /= 45;
+    float noise_level = (ref_hi + ref_lo) / 2;
+    return 10 * log10f(sig_level / noise_level);        /* sdrx.cpp:567 */
+}
+
+void sdrx_oracle_channel_chunk(sdrx_oracle_channel *c, const float *iq, const float *window, const float *pb,
+                               const float *ramp_up, const float *ramp_down, float *audio)
+{
+    /* audio part, sdrx.cpp:455-503 (per sample; pan-mix left out: mono, weight 1) */
+    for (unsigned i = 0; i < SDRX_ORACLE_FFT_SIZE; i++) {
+        float y[2];
+        sdrx_oracle_agc_adjust(&c->agc, iq + 2 * i, 1, y);                 /* always, sdrx.cpp:457 */
+        float s = 0.0f;
+        if (c->sql_state == 1) {                                           /* sdrx.cpp:458-468 */
+            sdrx_oracle_demod_am(y, 1, &s);
+            sdrx_oracle_lfagc_adjust(&c->agc_lf, &s, 1, &s);
+            if (c->sql_state_prev == 0) s = ramp_up[i] * s;
+        } else if (c->sql_state_prev == 1) {                               /* sdrx.cpp:498-502 */
+            sdrx_oracle_demod_am(y, 1, &s);
+            sdrx_oracle_lfagc_adjust(&c->agc_lf, &s, 1, &s);
+            s = ramp_down[i] * s;
+        }
+        audio[i] = s;
+    }
+    c->sql_state_prev = c->sql_state;                                      /* sdrx.cpp:536 */
+    /* squelch part, sdrx.cpp:538-573 */
+    c->snr = sdrx_oracle_squelch_snr(iq, window, pb);
+    if (c->snr > c->sql_level + 3 || c->sql_level == 0.0f) c->sql_state = 1;
+    else if (c->snr < c->sql_level) c->sql_state = 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Synthetic IQ (ours).  Integer-exact uniform noise from a       */
 /* counter-based SplitMix64 plus optional AM carriers placed on channel centres */
 /* with the channels' own translator tables (so no libm in the generator).     */

@@ -83,6 +83,28 @@ void sdrx_oracle_bank_process(sdrx_oracle_bank *b, const float *in_iq, size_t in
                               size_t *out_len, int threads);
 void sdrx_oracle_bank_destroy(sdrx_oracle_bank *b);
 
+/* ---- squelch + squelch-gated audio of one channel for one 512-sample chunk
+ *      (reference src/sdrx.cpp:455-503 audio part, 533-573 squelch part, window 896-900).
+ *      PARITY UNPINNED for the FFT: the reference uses FFTW3f (absent here); this restatement evaluates the
+ *      same 512-point forward DFT directly in double precision.  Everything around the transform follows the
+ *      reference's float arithmetic. ---- */
+#define SDRX_ORACLE_FFT_SIZE 512
+typedef struct {
+    sdrx_oracle_agc agc, agc_lf;
+    float sql_level;
+    int   sql_state, sql_state_prev;     /* 0 = SQL_CLOSED, 1 = SQL_OPEN (sdrx.cpp:149) */
+    float snr;                           /* last SNR in dB */
+} sdrx_oracle_channel;
+
+void  sdrx_oracle_hamming_window(float *w /* 512 */);
+void  sdrx_oracle_channel_init(sdrx_oracle_channel *c, float sql_level, int use_lf_agc);
+float sdrx_oracle_squelch_snr(const float *iq /* 512 complex */, const float *window, const float *passband_shape);
+/* One chunk: audio[512] (mono, before the pan-mix) with the squelch state left by the previous chunk, then the
+ * squelch update from this chunk's (pre-AGC) IQ. */
+void  sdrx_oracle_channel_chunk(sdrx_oracle_channel *c, const float *iq, const float *window,
+                                const float *passband_shape, const float *ramp_up, const float *ramp_down,
+                                float *audio);
+
 /* ---- synthetic IQ generator (ours; not a reference function) ---- */
 void sdrx_oracle_synth_iq(uint64_t seed, uint64_t n_start, size_t n, float noise_amp,
                           int n_carriers, const float *const *carrier_tables_iq, int N,

@@ -49,7 +49,9 @@ class _Cfg(C.Structure):
                 ("agc", AgcParams), ("lf_agc", AgcParams),
                 ("device", C.c_int32), ("stream", C.c_void_p),
                 ("max_in_len", C.c_uint32), ("block_hint", C.c_uint32),
-                ("audio_fir_taps", C.POINTER(C.c_float)), ("n_audio_fir_taps", C.c_uint32), ("audio_fir_gain_db", C.c_float)]
+                ("audio_fir_taps", C.POINTER(C.c_float)), ("n_audio_fir_taps", C.c_uint32), ("audio_fir_gain_db", C.c_float),
+                ("sql_level", C.POINTER(C.c_float)), ("passband_shape", C.POINTER(C.c_float)),
+                ("ramp_up", C.POINTER(C.c_float)), ("ramp_down", C.POINTER(C.c_float))]
 
 
 class BankInfo(C.Structure):
@@ -114,6 +116,7 @@ def load_library():
     L.sdrxgpu_bank_synchronize.argtypes = [vp]
     L.sdrxgpu_bank_get_info.argtypes = [vp, C.POINTER(BankInfo)]
     L.sdrxgpu_bank_get_gains.argtypes = [vp, vp, vp]
+    L.sdrxgpu_bank_get_squelch.argtypes = [vp, vp, vp]
     L.sdrxgpu_bank_profile_enable.argtypes = [vp, C.c_int]
     L.sdrxgpu_bank_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sdrxgpu_bank_profile_reset.argtypes = [vp]
@@ -124,7 +127,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "sdrxgpu_agc_params_sdrx", "sdrxgpu_make_translator", "sdrxgpu_bank_create", "sdrxgpu_bank_destroy",
     "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_flush", "sdrxgpu_bank_ingest_buffer",
-    "sdrxgpu_host_register", "sdrxgpu_host_unregister", "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_profile_enable",
+    "sdrxgpu_host_register", "sdrxgpu_host_unregister", "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_get_squelch", "sdrxgpu_bank_profile_enable",
     "sdrxgpu_bank_profile_read", "sdrxgpu_bank_profile_reset", "sdrxgpu_strerror", "sdrxgpu_last_error",
     "sdrxgpu_version",
 ]
@@ -190,7 +193,7 @@ class ChannelBank:
 
     def __init__(self, translators, stages, lf_agc=False, agc=None, agc_lf=None, device=-1, stream=None,
                  max_in_len=0, block_hint=0, pipelined=False, ftfir=False,
-                 audio_fir=None, audio_fir_gain_db=0.0):
+                 audio_fir=None, audio_fir_gain_db=0.0, squelch=None):
         L = load_library()
         self._L = L
         n_ch = len(translators)
@@ -224,6 +227,12 @@ class ChannelBank:
             cfg.audio_fir_taps = self._fir.ctypes.data_as(C.POINTER(C.c_float))
             cfg.n_audio_fir_taps = len(self._fir)
             cfg.audio_fir_gain_db = audio_fir_gain_db
+        if squelch is not None:
+            # squelch = (sql_level per channel, passband_shape, ramp_up, ramp_down)
+            self._sq = [np.ascontiguousarray(a_, dtype=np.float32) for a_ in squelch]
+            assert len(self._sq[0]) == n_ch and all(len(t) == 512 for t in self._sq[1:])
+            fp = C.POINTER(C.c_float)
+            cfg.sql_level, cfg.passband_shape, cfg.ramp_up, cfg.ramp_down = [t.ctypes.data_as(fp) for t in self._sq]
         h = C.c_void_p()
         _check(L.sdrxgpu_bank_create(C.byref(cfg), C.byref(h)), "sdrxgpu_bank_create")
         self._h = h
@@ -266,6 +275,13 @@ class ChannelBank:
         b = np.empty(self.n_channels, dtype=np.float32)
         _check(self._L.sdrxgpu_bank_get_gains(self._h, a.ctypes.data, b.ctypes.data), "sdrxgpu_bank_get_gains")
         return a, b
+
+    def squelch_state(self):
+        """(snr_db[n_ch], state[n_ch]) after the last chunk (sdrx.cpp:567-573)."""
+        snr = np.empty(self.n_channels, dtype=np.float32)
+        st = np.empty(self.n_channels, dtype=np.uint8)
+        _check(self._L.sdrxgpu_bank_get_squelch(self._h, snr.ctypes.data, st.ctypes.data), "sdrxgpu_bank_get_squelch")
+        return snr, st
 
     # ---- the hot path ----
     def process(self, iq, out_stride=None, want_iq=True, want_audio=True, iq_out=None, audio_out=None):

@@ -77,6 +77,19 @@ def audio_bpf_taps() -> np.ndarray:
     return _hex_to_f32(_load()["audio_bpf"]["taps"])
 
 
+def squelch_tables():
+    """(passband_shape[512], ramp_up[512], ramp_down[512]) -- reference src/coeffs.hpp:2018, :2541, :3064."""
+    d = _load()["squelch"]
+    return _hex_to_f32(d["passband_shape"]), _hex_to_f32(d["ramp_up"]), _hex_to_f32(d["ramp_down"])
+
+
+def hamming_window(n: int = 512) -> np.ndarray:
+    """FFT window of the squelch, reference src/sdrx.cpp:896-900: 0.54f - 0.46f*cos((2.0f*M_PI*n)/FFT_SIZE),
+    cos evaluated in double (M_PI is a double), result narrowed to float."""
+    k = np.arange(n, dtype=np.float64)
+    return (np.float32(0.54) - (np.float32(0.46).astype(np.float64) * np.cos((2.0 * np.pi * k) / n))).astype(np.float32)
+
+
 def offsets_for_config(name: str):
     """Channel offset sets (in 8.33 kHz steps from the tuner) of the BASELINE.json configs."""
     if name == "c1":       # 1 channel, 2.4 MS/s

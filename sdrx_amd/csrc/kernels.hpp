@@ -581,13 +581,18 @@ struct AgcArgs {
     int lf_active;
     int audio_vec;           // 1: audio rows are 16-byte aligned (vector stores)
     AgcParams agc, lf;
+    // squelch gating (sdrx.cpp:458-503); sql == nullptr: every channel is treated as open
+    const uchar2 *sql;       // [n_ch] {state, state_prev} left by the previous chunk
+    const float *ramp_up, *ramp_down;   // [512]
 };
 
 struct AgcState {
     float g, pw, gl, pl;
 };
 
-__device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const AgcParams &A, const AgcParams &Lf, int lf_active)
+// mode: 0 = squelch closed (IF AGC only, silence), 1 = open, 2 = just opened (ramp_up), 3 = just closed (ramp_down)
+__device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const AgcParams &A, const AgcParams &Lf, int lf_active,
+                                          int mode = 1, float ramp = 1.0f)
 {
     // AGC::adjust, agc.hpp:48-69 (same operation order, unfused)
     const float yr = __fmul_rn(x.x, st.g), yi = __fmul_rn(x.y, st.g);
@@ -599,13 +604,19 @@ __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const Ag
     // Demod::demod AM: std::abs, sdrx.cpp:178-180.  v_sqrt_f32 (1 ulp) instead of the correctly rounded
     // software sequence: this loop is a 512-step dependency chain, its latency is the kernel's run time
     const float s = __builtin_amdgcn_sqrtf(nrm);
-    // LfAGC::adjust, agc.hpp:106-131
+    // LfAGC::adjust, agc.hpp:106-131 -- only while the squelch is open or ramping down (sdrx.cpp:458-463, 498-501)
     const float sl = __fmul_rn(s, st.gl);
-    st.pl = __fadd_rn(st.pl, __fmul_rn(Lf.alpha, __fsub_rn(__fmul_rn(sl, sl), st.pl)));
-    const float errl = __fsub_rn(Lf.reference, __builtin_amdgcn_sqrtf(st.pl));
-    st.gl = __fadd_rn(st.gl, __fmul_rn(errl > 0.0f ? Lf.decay : Lf.attack, errl));
-    st.gl = st.gl < Lf.min_gain ? Lf.min_gain : (st.gl > Lf.max_gain ? Lf.max_gain : st.gl);
-    return lf_active ? sl : s;
+    const float pl = __fadd_rn(st.pl, __fmul_rn(Lf.alpha, __fsub_rn(__fmul_rn(sl, sl), st.pl)));
+    const float errl = __fsub_rn(Lf.reference, __builtin_amdgcn_sqrtf(pl));
+    float gl = __fadd_rn(st.gl, __fmul_rn(errl > 0.0f ? Lf.decay : Lf.attack, errl));
+    gl = gl < Lf.min_gain ? Lf.min_gain : (gl > Lf.max_gain ? Lf.max_gain : gl);
+    if (mode != 0) {
+        st.pl = pl;
+        st.gl = gl;
+    }
+    float out = lf_active ? sl : s;
+    if (mode >= 2) out = __fmul_rn(ramp, out);           // ramp_up[i] * s / ramp_down[i] * s
+    return mode != 0 ? out : 0.0f;
 }
 
 __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
@@ -616,6 +627,13 @@ __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
     float *__restrict__ out = a.audio + (size_t)ch * a.out_stride;
     const float4 s4 = a.state[ch];
     AgcState st = {s4.x, s4.y, s4.z, s4.w};
+    int mode = 1;
+    const float *__restrict__ ramp = nullptr;
+    if (a.sql) {
+        const uchar2 q = a.sql[ch];
+        mode = q.x ? (q.y ? 1 : 2) : (q.y ? 3 : 0);
+        ramp = (mode == 2) ? a.ramp_up : a.ramp_down;
+    }
 
     const int n8 = a.n_out & ~7;
     const float4 *__restrict__ row4 = reinterpret_cast<const float4 *>(row);
@@ -635,8 +653,9 @@ __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
         float y[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            y[2 * k + 0] = agc_step(make_float2(cur[k].x, cur[k].y), st, a.agc, a.lf, a.lf_active);
-            y[2 * k + 1] = agc_step(make_float2(cur[k].z, cur[k].w), st, a.agc, a.lf, a.lf_active);
+            const float r0 = mode >= 2 ? ramp[(base + 2 * k) & 511] : 1.0f, r1 = mode >= 2 ? ramp[(base + 2 * k + 1) & 511] : 1.0f;
+            y[2 * k + 0] = agc_step(make_float2(cur[k].x, cur[k].y), st, a.agc, a.lf, a.lf_active, mode, r0);
+            y[2 * k + 1] = agc_step(make_float2(cur[k].z, cur[k].w), st, a.agc, a.lf, a.lf_active, mode, r1);
         }
         if (a.audio_vec) {
             reinterpret_cast<float4 *>(out + base)[0] = make_float4(y[0], y[1], y[2], y[3]);
@@ -646,8 +665,90 @@ __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
             for (int k = 0; k < 8; k++) out[base + k] = y[k];
         }
     }
-    for (int i = n8; i < a.n_out; i++) out[i] = agc_step(row[i], st, a.agc, a.lf, a.lf_active);
+    for (int i = n8; i < a.n_out; i++) out[i] = agc_step(row[i], st, a.agc, a.lf, a.lf_active, mode, mode >= 2 ? ramp[i & 511] : 1.0f);
     a.state[ch] = make_float4(st.g, st.pw, st.gl, st.pl);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_squelch: per channel, per 512-output chunk: Hamming window x 512-point forward FFT of the decimated
+// (pre-AGC) IQ, in-band power vs. shaped out-of-band noise power, SNR in dB, open/close with 3 dB of
+// hysteresis (reference src/sdrx.cpp:533-573; FFTW there, an in-LDS radix-2 FFT here).  One wave per channel.
+// ------------------------------------------------------------------------------------------
+struct SquelchArgs {
+    const float2 *iq;          // [n_ch][iq_stride], 512 valid outputs
+    const float *window;       // [512]
+    const float *pb;           // [512] passband_shape
+    const float2 *tw;          // [256] exp(-j 2 pi k / 512)
+    const float *sql_level;    // [n_ch]
+    float *snr;                // [n_ch]
+    uchar2 *sql;               // [n_ch] {state, state_prev}
+    int n_ch, iq_stride;
+};
+
+__global__ __launch_bounds__(256) void k_squelch(const SquelchArgs a)
+{
+    constexpr int N = 512, LOGN = 9;
+    __shared__ float2 buf[4][N];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + wave;
+    const bool ok = ch < a.n_ch;
+    float2 *b = buf[wave];
+    // windowed input, stored bit-reversed for the decimation-in-time butterflies
+    for (int i = lane; i < N; i += kWave) {
+        float2 v = make_float2(0.f, 0.f);
+        if (ok) {
+            const float2 x = a.iq[(size_t)ch * a.iq_stride + i];
+            const float w = a.window[i];
+            v = make_float2(x.x * w, x.y * w);               // fft_in[i] = iq * window[i], sdrx.cpp:533
+        }
+        b[__brev((unsigned)i) >> (32 - LOGN)] = v;
+    }
+    __syncthreads();
+    for (int s = 1; s <= LOGN; s++) {
+        const int half = 1 << (s - 1);
+        for (int bf = lane; bf < N / 2; bf += kWave) {
+            const int j = bf & (half - 1);
+            const int i0 = ((bf >> (s - 1)) << s) + j, i1 = i0 + half;
+            const float2 w = a.tw[j << (LOGN - s)];
+            const float2 u = b[i0], v = b[i1];
+            const float2 t = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            b[i0] = make_float2(u.x + t.x, u.y + t.y);
+            b[i1] = make_float2(u.x - t.x, u.y - t.y);
+        }
+        __syncthreads();
+    }
+    // power sums, sdrx.cpp:541-565 (per-bin terms as there; the order of the additions differs)
+    float sig = 0.f, hi = 0.f, lo = 0.f;
+    for (int i = 3 + lane; i < 91; i += kWave) {
+        const float2 p = b[i], q = b[N - i];
+        sig += p.x * p.x + p.y * p.y;
+        sig += q.x * q.x + q.y * q.y;
+    }
+    for (int i = 112 + lane; i < 157; i += kWave) {
+        const float2 p = b[i], q = b[N - i];
+        const float wp = a.pb[i], wq = a.pb[N - i];
+        const float pr = p.x * wp, pi = p.y * wp, qr = q.x * wq, qi = q.y * wq;
+        hi += pr * pr + pi * pi;
+        lo += qr * qr + qi * qi;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        sig += __shfl_xor(sig, o);
+        hi += __shfl_xor(hi, o);
+        lo += __shfl_xor(lo, o);
+    }
+    if (ok && lane == 0) {
+        const float sig_level = sig / 176;
+        const float noise_level = (hi / 45 + lo / 45) / 2;
+        const float snr = 10 * log10f(sig_level / noise_level);
+        const float lvl = a.sql_level[ch];
+        uchar2 st = a.sql[ch];
+        st.y = st.x;                                          // sql_state_prev = sql_state, sdrx.cpp:536
+        if (snr > lvl + 3 || lvl == 0.0f) st.x = 1;           // sdrx.cpp:569-573
+        else if (snr < lvl) st.x = 0;
+        a.sql[ch] = st;
+        a.snr[ch] = snr;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

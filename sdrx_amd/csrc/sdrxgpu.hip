@@ -213,6 +213,11 @@ struct sdrxgpu_bank {
     float *d_audio_keep = nullptr;
     float4 *d_state = nullptr;
     float *d_fir_taps = nullptr, *d_fir_hist = nullptr;   // optional audio FIR
+    // optional squelch
+    bool squelch = false;
+    uchar2 *d_sql = nullptr;
+    float *d_snr = nullptr, *d_sql_level = nullptr, *d_sq_tabs = nullptr;   // d_sq_tabs: window | passband | ramp_up | ramp_down
+    float2 *d_tw = nullptr;
     int fir_T = 0;
     size_t device_bytes = 0;
 
@@ -272,6 +277,11 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_keep);
     (void)hipFree(b->d_audio_keep);
     (void)hipFree(b->d_state);
+    (void)hipFree(b->d_sql);
+    (void)hipFree(b->d_snr);
+    (void)hipFree(b->d_sql_level);
+    (void)hipFree(b->d_sq_tabs);
+    (void)hipFree(b->d_tw);
     (void)hipFree(b->d_fir_taps);
     (void)hipFree(b->d_fir_hist);
     if (b->owns_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -288,6 +298,10 @@ static int init_state(sdrxgpu_bank *b)
     HIPCHK(hipMemsetAsync(b->d_hist[0], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
     HIPCHK(hipMemsetAsync(b->d_hist[1], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
     b->hist_cur = 0;
+    if (b->squelch) {
+        HIPCHK(hipMemsetAsync(b->d_sql, 0, (size_t)b->n_ch * sizeof(uchar2), b->stream));   // SQL_CLOSED, sdrx.cpp:210
+        HIPCHK(hipMemsetAsync(b->d_snr, 0, (size_t)b->n_ch * sizeof(float), b->stream));
+    }
     if (b->fir_T) HIPCHK(hipMemsetAsync(b->d_fir_hist, 0, (size_t)b->n_ch * (b->fir_T - 1) * sizeof(float), b->stream));
     std::vector<float4> st(b->n_ch, make_float4(b->agc.init_gain, b->agc.init_power, b->lf.init_gain, b->lf.init_power));
     HIPCHK(hipMemcpyAsync(b->d_state, st.data(), st.size() * sizeof(float4), hipMemcpyHostToDevice, b->stream));
@@ -531,6 +545,38 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "hipFuncSetAttribute(k_tail) failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (cfg->sql_level) {
+        if (!cfg->passband_shape || !cfg->ramp_up || !cfg->ramp_down) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: squelch needs passband_shape, ramp_up and ramp_down (512 floats each)");
+        }
+        b->squelch = true;
+        std::vector<float> tabs(4 * 512);
+        for (unsigned n = 0; n < 512; n++) {
+            tabs[n] = 0.54f - 0.46f * std::cos((2.0f * M_PI * n) / 512);        // Hamming, sdrx.cpp:896-900 verbatim
+            tabs[512 + n] = cfg->passband_shape[n];
+            tabs[1024 + n] = cfg->ramp_up[n];
+            tabs[1536 + n] = cfg->ramp_down[n];
+        }
+        std::vector<float2> tw(256);
+        for (int k = 0; k < 256; k++)
+            tw[k] = make_float2((float)std::cos(-2.0 * M_PI * k / 512.0), (float)std::sin(-2.0 * M_PI * k / 512.0));
+        if ((rc = dev_alloc(b, (void **)&b->d_sql, (size_t)b->n_ch * sizeof(uchar2))) ||
+            (rc = dev_alloc(b, (void **)&b->d_snr, (size_t)b->n_ch * sizeof(float))) ||
+            (rc = dev_alloc(b, (void **)&b->d_sql_level, (size_t)b->n_ch * sizeof(float))) ||
+            (rc = dev_alloc(b, (void **)&b->d_sq_tabs, tabs.size() * sizeof(float))) ||
+            (rc = dev_alloc(b, (void **)&b->d_tw, tw.size() * sizeof(float2)))) {
+            free_bank(b);
+            return rc;
+        }
+        hipError_t e = hipMemcpy(b->d_sql_level, cfg->sql_level, (size_t)b->n_ch * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->d_sq_tabs, tabs.data(), tabs.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "squelch table upload failed: %s", hipGetErrorString(e));
         }
     }
     if (cfg->n_audio_fir_taps) {
@@ -847,6 +893,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     job->valid = false;
     if (out_off + (size_t)t.n_b > out_stride && (d_iq_out || d_audio_out))
         return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride);
+    if (b->squelch && t.n_b != 512)
+        return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a bank with squelch takes whole 512-output chunks (this call produces %d)", t.n_b);
     t.hist_in = b->d_hist[b->hist_cur];
     t.hist_out = b->d_hist[b->hist_cur ^ 1];
     t.iq_out = d_iq_out ? d_iq_out + out_off : nullptr;
@@ -880,9 +928,26 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         };
         fill(g.agc, b->agc);
         fill(g.lf, b->lf);
+        g.sql = b->squelch ? b->d_sql : nullptr;
+        g.ramp_up = b->squelch ? b->d_sq_tabs + 1024 : nullptr;
+        g.ramp_down = b->squelch ? b->d_sq_tabs + 1536 : nullptr;
         ProfScope ps(b, SDRXGPU_K_AGC);
         hipLaunchKernelGGL(k_agc, dim3((b->n_ch + kWave - 1) / kWave), dim3(kWave), 0, b->stream, g);
         HIPCHK(hipGetLastError());
+        if (b->squelch) {
+            SquelchArgs q;
+            q.iq = b->d_keep;
+            q.iq_stride = b->keep_stride;
+            q.window = b->d_sq_tabs;
+            q.pb = b->d_sq_tabs + 512;
+            q.tw = b->d_tw;
+            q.sql_level = b->d_sql_level;
+            q.snr = b->d_snr;
+            q.sql = b->d_sql;
+            q.n_ch = (int)b->n_ch;
+            hipLaunchKernelGGL(k_squelch, dim3((b->n_ch + 3) / 4), dim3(256), 0, b->stream, q);
+            HIPCHK(hipGetLastError());
+        }
         if (b->fir_T) {
             AudioFirArgs f;
             f.audio = g.audio;
@@ -1023,5 +1088,19 @@ extern "C" int sdrxgpu_host_unregister(void *ptr)
 {
     if (!ptr) return fail(SDRXGPU_ERR_INVALID_ARG, "host_unregister: null pointer");
     HIPCHK(hipHostUnregister(ptr));
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_get_squelch(sdrxgpu_bank *b, float *snr_db, unsigned char *state)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_squelch: null bank");
+    if (!b->squelch) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_squelch: the bank was created without squelch");
+    HIPCHK(hipSetDevice(b->device));
+    std::vector<uchar2> st(b->n_ch);
+    if (snr_db) HIPCHK(hipMemcpyAsync(snr_db, b->d_snr, (size_t)b->n_ch * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(st.data(), b->d_sql, st.size() * sizeof(uchar2), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (state)
+        for (uint32_t c = 0; c < b->n_ch; c++) state[c] = st[c].x;
     return SDRXGPU_OK;
 }

@@ -427,6 +427,46 @@ def test_lf_agc_and_custom_agc_parameters(oracle):
     assert rel_err(au, ref) <= RTOL
 
 
+def test_squelch_and_gated_audio_vs_oracle(oracle):
+    """Squelch (sdrx.cpp:533-573) + the audio gating by it (458-503) over a carrier that comes and goes: closed ->
+    opening (ramp_up) -> open -> closing (ramp_down) -> closed, plus an always-open (level 0) and a never-opening channel.
+    FFT parity is UNPINNED (FFTW absent): the oracle evaluates the same DFT directly in double precision."""
+    from oracle import ffi as offi
+    ch = chains.chain("10")
+    offs = [37, -100, 5]
+    levels = [9.0, 0.0, 9.0]
+    tabs = sb.translators_for(ch, offs)
+    pb, ru, rd = chains.squelch_tables()
+    win = offi.hamming_window(oracle)
+    assert np.array_equal(win.view(np.uint32), chains.hamming_window().view(np.uint32))
+    on = [False, False, True, True, True, False, False, False]
+    blocks = [synth.synth_iq(5, b * ch.block_len, ch.block_len, 0.25, [tabs[0]] if c else [], [0.2] if c else [], ch.N, 10000)
+              for b, c in enumerate(on)]
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), squelch=(np.array(levels, np.float32), pb, ru, rd))
+    ref_ch = [offi.SquelchChannel(oracle, lv, win, pb, ru, rd) for lv in levels]
+    ref_msd = [oracle.msd(t, ch.stage_tuples()) for t in tabs]
+    seen_states = set()
+    for b, x in enumerate(blocks):
+        iq, au = bank.process(x)
+        snr, st = bank.squelch_state()
+        for c in range(3):
+            y = ref_msd[c].decimate(x)
+            r_au, r_snr, r_st = ref_ch[c].chunk(y)
+            assert rel_err(iq[c], y) <= RTOL
+            assert abs(float(snr[c]) - r_snr) < 2e-3, (b, c, snr[c], r_snr)
+            assert int(st[c]) == r_st, (b, c)
+            scale = max(float(np.sqrt(np.mean(r_au ** 2))), 1e-3)
+            assert float(np.max(np.abs(au[c] - r_au))) / scale <= 2e-5, (b, c)
+        seen_states.add((int(st[0]), bool(np.any(au[0] != 0))))
+    assert (1, True) in seen_states and (0, False) in seen_states and (0, True) in seen_states   # open, closed, ramp-down
+    assert np.all(bank.squelch_state()[1][[1]] == 1)       # level 0: always open
+    # whole chunks only
+    with pytest.raises(sb.SdrxGpuError) as e:
+        bank.process(blocks[0][:1000])
+    assert e.value.code == -5
+    bank.close()
+
+
 def test_error_behaviour():
     ch = chains.chain("10")
     tabs = sb.translators_for(ch, [5])

@@ -186,3 +186,32 @@ def test_ftfir_relation_to_mixer_path(oracle):
     ratio = b[100:] / a[100:]
     pred = 2.0 * np.exp(2j * np.pi * off * (ch.stages[0].m - 1) * ch.z / ch.N)
     assert np.max(np.abs(ratio - pred)) < 2e-3
+
+
+def test_squelch_restatement_vs_numpy_fft(oracle):
+    """The squelch restatement (sdrx.cpp:533-573; direct DFT in place of FFTW -> parity unpinned) against an
+    independent numpy.fft evaluation of the same formula, plus the state machine with its 3 dB hysteresis."""
+    from oracle import ffi as offi
+    ch = chains.chain("10")
+    pb, ru, rd = chains.squelch_tables()
+    win = offi.hamming_window(oracle)
+    assert np.array_equal(win.view(np.uint32), chains.hamming_window().view(np.uint32))
+    assert abs(float(ru[100]) - (1 - np.exp(-1.0))) < 1e-6 and abs(float(rd[100]) - np.exp(-1.0)) < 1e-6
+    t = oracle.make_translator(ch.N, ch.z, 37)
+    sc = offi.SquelchChannel(oracle, 9.0, win, pb, ru, rd)
+    msd = oracle.msd(t, ch.stage_tuples())
+    states = []
+    for b, amp in enumerate([0.0, 0.2, 0.2, 0.0, 0.0]):
+        x = synth.synth_iq(5, b * ch.block_len, ch.block_len, 0.25, [t] if amp else [], [amp] if amp else [], ch.N, 10000)
+        y = msd.decimate(x)
+        audio, snr, st = sc.chunk(y)
+        P = np.abs(np.fft.fft(y.astype(np.complex128) * win)) ** 2
+        sig = (P[3:91].sum() + P[512 - 90:512 - 2].sum()) / 176
+        w2 = pb.astype(np.float64) ** 2
+        hi = (P[112:157] * w2[112:157]).sum() / 45
+        lo = (P[512 - 156:512 - 111] * w2[512 - 156:512 - 111]).sum() / 45
+        assert abs(snr - 10 * np.log10(sig / ((hi + lo) / 2))) < 1e-3
+        states.append((st, bool(np.any(audio != 0))))
+    # closed/silent, opens after the first carrier chunk (audio still silent in it), open with audio,
+    # closes after the first noise chunk (that chunk still has audio), then ramp-down chunk, i.e. audio once more
+    assert states == [(0, False), (1, False), (1, True), (0, True), (0, True)]
