@@ -590,7 +590,9 @@ struct AgcState {
     float g, pw, gl, pl;
 };
 
-// mode: 0 = squelch closed (IF AGC only, silence), 1 = open, 2 = just opened (ramp_up), 3 = just closed (ramp_down)
+// mode: 0 = squelch closed (IF AGC only, silence), 1 = open, 2 = just opened (ramp_up), 3 = just closed (ramp_down).
+// Branch-free: this is a 512-step dependency chain, a branch per step would sit on its critical path.
+template <bool SQ>
 __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const AgcParams &A, const AgcParams &Lf, int lf_active,
                                           int mode = 1, float ramp = 1.0f)
 {
@@ -610,15 +612,21 @@ __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const Ag
     const float errl = __fsub_rn(Lf.reference, __builtin_amdgcn_sqrtf(pl));
     float gl = __fadd_rn(st.gl, __fmul_rn(errl > 0.0f ? Lf.decay : Lf.attack, errl));
     gl = gl < Lf.min_gain ? Lf.min_gain : (gl > Lf.max_gain ? Lf.max_gain : gl);
-    if (mode != 0) {
+    float out = lf_active ? sl : s;
+    if constexpr (SQ) {
+        const bool live = mode != 0;
+        st.pl = live ? pl : st.pl;
+        st.gl = live ? gl : st.gl;
+        out = __fmul_rn(ramp, out);           // ramp = ramp_up[i] / ramp_down[i] / 1 (open) / 0 (closed)
+        return live ? out : 0.0f;
+    } else {
         st.pl = pl;
         st.gl = gl;
+        return out;
     }
-    float out = lf_active ? sl : s;
-    if (mode >= 2) out = __fmul_rn(ramp, out);           // ramp_up[i] * s / ramp_down[i] * s
-    return mode != 0 ? out : 0.0f;
 }
 
+template <bool SQ>
 __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
 {
     const int ch = blockIdx.x * kWave + threadIdx.x;
@@ -628,34 +636,50 @@ __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
     const float4 s4 = a.state[ch];
     AgcState st = {s4.x, s4.y, s4.z, s4.w};
     int mode = 1;
-    const float *__restrict__ ramp = nullptr;
-    if (a.sql) {
+    const float *__restrict__ ramp = a.ramp_down;
+    if constexpr (SQ) {
         const uchar2 q = a.sql[ch];
         mode = q.x ? (q.y ? 1 : 2) : (q.y ? 3 : 0);
         ramp = (mode == 2) ? a.ramp_up : a.ramp_down;
     }
+    const bool ramped = SQ && mode >= 2;
 
     const int n8 = a.n_out & ~7;
     const float4 *__restrict__ row4 = reinterpret_cast<const float4 *>(row);
     float4 nx[4];
+    float4 nr[2];
     if (n8 > 0) {
 #pragma unroll
         for (int k = 0; k < 4; k++) nx[k] = row4[k];
+        if constexpr (SQ) {
+            nr[0] = reinterpret_cast<const float4 *>(ramp)[0];
+            nr[1] = reinterpret_cast<const float4 *>(ramp)[1];
+        }
     }
     for (int base = 0; base < n8; base += 8) {
         float4 cur[4];
+        float r[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
 #pragma unroll
         for (int k = 0; k < 4; k++) cur[k] = nx[k];
+        if constexpr (SQ) {
+            if (ramped) {
+                r[0] = nr[0].x; r[1] = nr[0].y; r[2] = nr[0].z; r[3] = nr[0].w;
+                r[4] = nr[1].x; r[5] = nr[1].y; r[6] = nr[1].z; r[7] = nr[1].w;
+            }
+        }
         if (base + 8 < n8) {
 #pragma unroll
             for (int k = 0; k < 4; k++) nx[k] = row4[(base + 8) / 2 + k];
+            if constexpr (SQ) {      // the ramp tables are 512 long = one chunk (n_out == 512 with squelch)
+                nr[0] = reinterpret_cast<const float4 *>(ramp)[((base + 8) & 511) / 4];
+                nr[1] = reinterpret_cast<const float4 *>(ramp)[((base + 8) & 511) / 4 + 1];
+            }
         }
         float y[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float r0 = mode >= 2 ? ramp[(base + 2 * k) & 511] : 1.0f, r1 = mode >= 2 ? ramp[(base + 2 * k + 1) & 511] : 1.0f;
-            y[2 * k + 0] = agc_step(make_float2(cur[k].x, cur[k].y), st, a.agc, a.lf, a.lf_active, mode, r0);
-            y[2 * k + 1] = agc_step(make_float2(cur[k].z, cur[k].w), st, a.agc, a.lf, a.lf_active, mode, r1);
+            y[2 * k + 0] = agc_step<SQ>(make_float2(cur[k].x, cur[k].y), st, a.agc, a.lf, a.lf_active, mode, r[2 * k]);
+            y[2 * k + 1] = agc_step<SQ>(make_float2(cur[k].z, cur[k].w), st, a.agc, a.lf, a.lf_active, mode, r[2 * k + 1]);
         }
         if (a.audio_vec) {
             reinterpret_cast<float4 *>(out + base)[0] = make_float4(y[0], y[1], y[2], y[3]);
@@ -665,7 +689,7 @@ __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
             for (int k = 0; k < 8; k++) out[base + k] = y[k];
         }
     }
-    for (int i = n8; i < a.n_out; i++) out[i] = agc_step(row[i], st, a.agc, a.lf, a.lf_active, mode, mode >= 2 ? ramp[i & 511] : 1.0f);
+    for (int i = n8; i < a.n_out; i++) out[i] = agc_step<SQ>(row[i], st, a.agc, a.lf, a.lf_active, mode, ramped ? ramp[i & 511] : 1.0f);
     a.state[ch] = make_float4(st.g, st.pw, st.gl, st.pl);
 }
 

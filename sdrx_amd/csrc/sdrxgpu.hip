@@ -929,10 +929,13 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         fill(g.agc, b->agc);
         fill(g.lf, b->lf);
         g.sql = b->squelch ? b->d_sql : nullptr;
-        g.ramp_up = b->squelch ? b->d_sq_tabs + 1024 : nullptr;
+        g.ramp_up = b->squelch ? b->d_sq_tabs + 1024 : nullptr;      // 16-byte aligned (offsets are multiples of 512 floats)
         g.ramp_down = b->squelch ? b->d_sq_tabs + 1536 : nullptr;
         ProfScope ps(b, SDRXGPU_K_AGC);
-        hipLaunchKernelGGL(k_agc, dim3((b->n_ch + kWave - 1) / kWave), dim3(kWave), 0, b->stream, g);
+        if (b->squelch)
+            hipLaunchKernelGGL(k_agc<true>, dim3((b->n_ch + kWave - 1) / kWave), dim3(kWave), 0, b->stream, g);
+        else
+            hipLaunchKernelGGL(k_agc<false>, dim3((b->n_ch + kWave - 1) / kWave), dim3(kWave), 0, b->stream, g);
         HIPCHK(hipGetLastError());
         if (b->squelch) {
             SquelchArgs q;
