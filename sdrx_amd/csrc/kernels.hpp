@@ -602,7 +602,7 @@ __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const Ag
     st.pw = __fadd_rn(st.pw, __fmul_rn(A.alpha, __fsub_rn(nrm, st.pw)));
     const float err = __fsub_rn(A.reference, st.pw);
     st.g = __fadd_rn(st.g, __fmul_rn(err > 0.0f ? A.decay : A.attack, err));
-    st.g = st.g < A.min_gain ? A.min_gain : (st.g > A.max_gain ? A.max_gain : st.g);
+    st.g = __builtin_amdgcn_fmed3f(st.g, A.min_gain, A.max_gain);      // the clamp of agc.hpp:63-67 in one instruction
     // Demod::demod AM: std::abs, sdrx.cpp:178-180.  v_sqrt_f32 (1 ulp) instead of the correctly rounded
     // software sequence: this loop is a 512-step dependency chain, its latency is the kernel's run time
     const float s = __builtin_amdgcn_sqrtf(nrm);
@@ -611,7 +611,7 @@ __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const Ag
     const float pl = __fadd_rn(st.pl, __fmul_rn(Lf.alpha, __fsub_rn(__fmul_rn(sl, sl), st.pl)));
     const float errl = __fsub_rn(Lf.reference, __builtin_amdgcn_sqrtf(pl));
     float gl = __fadd_rn(st.gl, __fmul_rn(errl > 0.0f ? Lf.decay : Lf.attack, errl));
-    gl = gl < Lf.min_gain ? Lf.min_gain : (gl > Lf.max_gain ? Lf.max_gain : gl);
+    gl = __builtin_amdgcn_fmed3f(gl, Lf.min_gain, Lf.max_gain);
     float out = lf_active ? sl : s;
     if constexpr (SQ) {
         const bool live = mode != 0;
