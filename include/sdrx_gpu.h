@@ -115,6 +115,17 @@ typedef struct {
     const float           *passband_shape;
     const float           *ramp_up;
     const float           *ramp_down;
+    /* Optional stereo mix-down of all channels' (gated) audio, the back half of alsa_write_cb: pan weights by
+     * Channel::pos (sdrx.cpp:469-497), the common FIR2 band-pass with its volume (sdrx.cpp:646, 880-881;
+     * fir.hpp:131-183) and the float -> S16 conversion (sdrx.cpp:649-656).  pan_pos == NULL: off.  pan_pos[c] in
+     * -2..2 as get_audio_pos returns it (sdrx.cpp:1024-1044; sdrxgpu_audio_pos); n_mix_fir_taps == 0: no filter.
+     * Each sdrxgpu_bank_process* call (at most max_in_len samples) then also leaves one stereo buffer on the
+     * device, read with sdrxgpu_bank_get_mix.  Channels are summed in channel order inside groups of 64 and the
+     * groups in order: identical to the reference's order for banks of <= 64 channels. */
+    const int8_t          *pan_pos;
+    const float           *mix_fir_taps;
+    uint32_t               n_mix_fir_taps;
+    float                  mix_fir_gain_db;
 } sdrxgpu_bank_cfg;
 
 typedef struct {
@@ -183,6 +194,16 @@ int sdrxgpu_bank_get_info(sdrxgpu_bank *bank, sdrxgpu_bank_info *info);
 /* Squelch SNR (dB) and state (0 closed / 1 open) per channel after the last chunk (what sdrx prints,
  * sdrx.cpp:593-634); either may be NULL. */
 int sdrxgpu_bank_get_squelch(sdrxgpu_bank *bank, float *snr_db, unsigned char *state);
+
+/* get_audio_pos of src/sdrx.cpp:1024-1044: stereo position -2..2 of channel channel_no out of num_channels. */
+int sdrxgpu_audio_pos(unsigned channel_no, unsigned num_channels);
+
+/* Stereo mix of the last process call (banks created with pan_pos): interleaved frames, slot 0 = the
+ * audio_buffer_float[i*2] of sdrx.cpp:472, as float (what FIR2 returned) and/or as S16 (what snd_pcm_writei
+ * takes, sdrx.cpp:659).  Either pointer may be NULL; *n_frames = frames available (512 per 32 ms block). */
+int sdrxgpu_bank_get_mix(sdrxgpu_bank *bank, float *mix_f32, int16_t *mix_s16, size_t cap_frames, size_t *n_frames);
+/* The same buffers on the device (valid in stream order after the process call). */
+int sdrxgpu_bank_mix_buffers(sdrxgpu_bank *bank, void **d_mix_f32, void **d_mix_s16, size_t *n_frames);
 
 /* AGC gains per channel (what sdrx prints with -v, sdrx.cpp:593-634); either may be NULL. */
 int sdrxgpu_bank_get_gains(sdrxgpu_bank *bank, float *agc_gain, float *lf_agc_gain);

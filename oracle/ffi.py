@@ -60,6 +60,10 @@ class _Lib:
             "fir_set_gain": (None, [C.c_void_p, C.c_float]),
             "fir_filter": (None, [C.c_void_p, _f32p, C.c_uint, _f32p]),
             "fir_destroy": (None, [C.c_void_p]),
+            "fir2_create": (C.c_void_p, [_f32p, C.c_uint]),
+            "fir2_set_gain": (None, [C.c_void_p, C.c_float]),
+            "fir2_filter": (None, [C.c_void_p, _f32p, C.c_uint, _f32p]),
+            "fir2_destroy": (None, [C.c_void_p]),
             "bank_create": (C.c_void_p, [C.c_int, C.POINTER(_f32p), C.POINTER(C.c_size_t), C.c_int, _u32p, _u32p,
                                          C.POINTER(_f32p), C.c_int, C.c_int]),
             "bank_process": (None, [C.c_void_p, _f32p, C.c_size_t, _f32p, _f32p, C.c_size_t,
@@ -104,6 +108,31 @@ class _Lib:
 
     def fir(self, taps, gain_db=None):
         return _FIR(self, taps, gain_db)
+
+    def fir2(self, taps, gain_db=None):
+        return _FIR(self, taps, gain_db, stereo=True)
+
+    # ---- stereo mix-down (restatement only: static code of sdrx.cpp) -----
+    def audio_pos(self, channel_no, num_channels):
+        assert self.prefix == "sdrx_oracle"
+        return int(self.lib.sdrx_oracle_audio_pos(C.c_uint(channel_no), C.c_uint(num_channels)))
+
+    def pan_mix(self, audio, pos):
+        """audio [n_ch, n] float32, pos [n_ch] int -> interleaved stereo [n, 2] float32."""
+        assert self.prefix == "sdrx_oracle"
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        p = np.ascontiguousarray(pos, dtype=np.int32)
+        out = np.empty((a.shape[1], 2), dtype=np.float32)
+        self.lib.sdrx_oracle_pan_mix(_fp(a), C.c_size_t(a.shape[1]), p.ctypes.data_as(C.POINTER(C.c_int)),
+                                     C.c_int(a.shape[0]), C.c_size_t(a.shape[1]), _fp(out))
+        return out
+
+    def to_s16(self, x):
+        assert self.prefix == "sdrx_oracle"
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(a.shape, dtype=np.int16)
+        self.lib.sdrx_oracle_to_s16(_fp(a), C.c_size_t(a.size), out.ctypes.data_as(C.POINTER(C.c_int16)))
+        return out
 
     def bank(self, translators, stages, use_ftfir=False, use_lf_agc=False):
         return _Bank(self, translators, stages, use_ftfir, use_lf_agc)
@@ -151,22 +180,25 @@ class _MSD:
 
 
 class _FIR:
-    def __init__(self, lib, taps, gain_db):
+    """FIR (mono) or FIR2 (interleaved stereo, x is [n, 2] or flat with 2 floats per frame)."""
+
+    def __init__(self, lib, taps, gain_db, stereo=False):
         self.lib = lib
+        self.k = "fir2" if stereo else "fir"
         t = np.ascontiguousarray(taps, dtype=np.float32)
-        self.h = lib._fn["fir_create"](_fp(t), len(t))
+        self.h = lib._fn[self.k + "_create"](_fp(t), len(t))
         if gain_db is not None:
-            lib._fn["fir_set_gain"](self.h, gain_db)
+            lib._fn[self.k + "_set_gain"](self.h, gain_db)
 
     def filter(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
         out = np.empty_like(x)
-        self.lib._fn["fir_filter"](self.h, _fp(x), len(x), _fp(out))
+        self.lib._fn[self.k + "_filter"](self.h, _fp(x), x.size, _fp(out))
         return out
 
     def __del__(self):
         if getattr(self, "h", None):
-            self.lib._fn["fir_destroy"](self.h)
+            self.lib._fn[self.k + "_destroy"](self.h)
             self.h = None
 
 

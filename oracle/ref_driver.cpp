@@ -121,6 +121,19 @@ void sdrx_ref_fir_filter(sdrx_ref_fir *f, const float *in, unsigned in_len, floa
 }
 void sdrx_ref_fir_destroy(sdrx_ref_fir *f) { delete f; }
 
+struct sdrx_ref_fir2 { FIR2 fir; };
+
+sdrx_ref_fir2 *sdrx_ref_fir2_create(const float *c, unsigned n)
+{
+    return new sdrx_ref_fir2{FIR2(std::vector<float>(c, c + n))};
+}
+void sdrx_ref_fir2_set_gain(sdrx_ref_fir2 *f, float gain_db) { f->fir.setGain(gain_db); }
+void sdrx_ref_fir2_filter(sdrx_ref_fir2 *f, const float *in, unsigned in_len, float *out)
+{
+    f->fir.filter(in, in_len, out);
+}
+void sdrx_ref_fir2_destroy(sdrx_ref_fir2 *f) { delete f; }
+
 // Channel bank = data_cb's loop (sdrx.cpp:342-345) + the AGC/demod/LfAGC lines of
 // alsa_write_cb (sdrx.cpp:457-463), squelch taken as open.
 struct sdrx_ref_bank {

@@ -460,6 +460,114 @@ void sdrx_oracle_fir_destroy(sdrx_oracle_fir *f)
 }
 
 /* ------------------------------------------------------------------------- */
+/* Stereo mix-down: FIR2 (fir.hpp:131-183), get_audio_pos (sdrx.cpp:1024-1044), */
+/* pan weights (sdrx.cpp:469-497), S16 conversion (sdrx.cpp:649-656).          */
+/* ------------------------------------------------------------------------- */
+struct sdrx_oracle_fir2 {
+    float   *c, *c_adj, *bufr, *bufl;
+    unsigned size, pos;
+    float    gain;
+};
+
+sdrx_oracle_fir2 *sdrx_oracle_fir2_create(const float *c, unsigned n)     /* fir.hpp:134 */
+{
+    sdrx_oracle_fir2 *f = (sdrx_oracle_fir2 *)calloc(1, sizeof(*f));
+    f->c = (float *)malloc(n * sizeof(float));
+    f->c_adj = (float *)malloc(n * sizeof(float));
+    f->bufr = (float *)calloc(n, sizeof(float));
+    f->bufl = (float *)calloc(n, sizeof(float));
+    memcpy(f->c, c, n * sizeof(float));
+    memcpy(f->c_adj, c, n * sizeof(float));
+    f->size = n;
+    return f;
+}
+
+void sdrx_oracle_fir2_set_gain(sdrx_oracle_fir2 *f, float gain_db)      /* fir.hpp:160-170 */
+{
+    f->gain = gain_db;
+    for (unsigned i = 0; i < f->size; i++) f->c_adj[i] = f->c[i] * powf(10.0f, f->gain / 20.0f);
+}
+
+void sdrx_oracle_fir2_filter(sdrx_oracle_fir2 *f, const float *in, unsigned in_len, float *out)
+{                                                                        /* fir.hpp:137-157 */
+    for (unsigned n = 0; n + 1 < in_len; n += 2) {
+        f->bufr[f->pos] = in[n];            /* even slot first, then the filter may overwrite it (in == out) */
+        f->bufl[f->pos] = in[n + 1];
+        if (++f->pos == f->size) f->pos = 0;
+        float a0 = 0.0f, a1 = 0.0f;
+        for (unsigned i = 0; i < f->size; i++) {
+            a0 += f->c_adj[i] * f->bufr[f->pos];
+            a1 += f->c_adj[i] * f->bufl[f->pos];
+            if (++f->pos == f->size) f->pos = 0;
+        }
+        out[n] = a0;
+        out[n + 1] = a1;
+    }
+}
+
+void sdrx_oracle_fir2_destroy(sdrx_oracle_fir2 *f)
+{
+    if (!f) return;
+    free(f->c);
+    free(f->c_adj);
+    free(f->bufr);
+    free(f->bufl);
+    free(f);
+}
+
+int sdrx_oracle_audio_pos(unsigned channel_no, unsigned num_channels)    /* sdrx.cpp:1024-1044 */
+{
+    const unsigned num_positions = 5;
+    const unsigned half = num_channels / 2;
+    const unsigned odd = (num_channels % 2) == 0 ? 0 : 1;
+    int pos = 0;
+    if (channel_no < num_channels) {
+        if (channel_no < half) {
+            float tmp = (float)(channel_no * num_positions) / (float)num_channels;
+            pos = (int)(floorf(tmp) - (float)(num_positions / 2));
+        } else if (channel_no == half && odd) {
+            pos = 0;
+        } else {
+            float tmp = (float)((num_channels - 1 - channel_no) * num_positions) / (float)num_channels;
+            pos = (int)((float)(num_positions / 2) - floorf(tmp));
+        }
+    }
+    return pos;
+}
+
+void sdrx_oracle_pan_mix(const float *audio, size_t stride, const int *pos, int n_channels, size_t n, float *mix)
+{
+    memset(mix, 0, 2 * n * sizeof(float));                               /* sdrx.cpp:451 */
+    for (int c = 0; c < n_channels; c++) {
+        float w0, w1;
+        switch (pos[c]) {                                                /* sdrx.cpp:471-497 */
+            case -2: w0 = 0.8f; w1 = 0.2f; break;
+            case -1: w0 = 0.6f; w1 = 0.4f; break;
+            case 1:  w0 = 0.4f; w1 = 0.6f; break;
+            case 2:  w0 = 0.2f; w1 = 0.8f; break;
+            default: w0 = 0.5f; w1 = 0.5f; break;
+        }
+        const float *row = audio + (size_t)c * stride;
+        for (size_t i = 0; i < n; i++) {
+            const float s = row[i];
+            mix[i * 2] += w0 * s;
+            mix[i * 2 + 1] += w1 * s;
+        }
+    }
+}
+
+void sdrx_oracle_to_s16(const float *in, size_t n, int16_t *out)         /* sdrx.cpp:649-656 */
+{
+    for (size_t i = 0; i < n; i++) {
+        int16_t s;
+        if (in[i] > 1.0f)       s = 32767;
+        else if (in[i] < -1.0f) s = -32767;
+        else                    s = (int16_t)(in[i] * 32767.0f);
+        out[i] = s;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Channel bank: data_cb's per-channel loop (sdrx.cpp:327-346) followed by the */
 /* per-sample AGC -> AM demod -> LfAGC of alsa_write_cb (sdrx.cpp:455-463),    */
 /* squelch taken as open.                                                      */

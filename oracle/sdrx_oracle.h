@@ -105,6 +105,24 @@ void  sdrx_oracle_channel_chunk(sdrx_oracle_channel *c, const float *iq, const f
                                 const float *passband_shape, const float *ramp_up, const float *ramp_down,
                                 float *audio);
 
+/* ---- stereo mix-down of the gated channel audio, the back half of alsa_write_cb ----
+ * FIR2 (reference src/fir.hpp:131-183): interleaved stereo FIR; pinned against the reference class through
+ * oracle/_ref (tests/test_oracle.py).  audio_pos / pan_mix / to_s16 restate three short blocks of sdrx.cpp that
+ * cannot be compiled on their own (static functions inside the ALSA program): PARITY UNPINNED beyond review. */
+typedef struct sdrx_oracle_fir2 sdrx_oracle_fir2;
+sdrx_oracle_fir2 *sdrx_oracle_fir2_create(const float *c, unsigned n);
+void  sdrx_oracle_fir2_set_gain(sdrx_oracle_fir2 *f, float gain_db);
+/* in_len counts floats (2 per frame), as the reference's; in and out may be the same array */
+void  sdrx_oracle_fir2_filter(sdrx_oracle_fir2 *f, const float *in, unsigned in_len, float *out);
+void  sdrx_oracle_fir2_destroy(sdrx_oracle_fir2 *f);
+/* get_audio_pos, reference src/sdrx.cpp:1024-1044 */
+int   sdrx_oracle_audio_pos(unsigned channel_no, unsigned num_channels);
+/* the `switch (ch.pos)` accumulation of sdrx.cpp:469-497 over all channels in channel order:
+ * mix[i*2], mix[i*2+1] += w(pos[c]) * audio[c*stride + i]; mix is zeroed first (sdrx.cpp:451) */
+void  sdrx_oracle_pan_mix(const float *audio, size_t stride, const int *pos, int n_channels, size_t n, float *mix);
+/* float -> S16 with the clamp of sdrx.cpp:649-656 */
+void  sdrx_oracle_to_s16(const float *in, size_t n, int16_t *out);
+
 /* ---- synthetic IQ generator (ours; not a reference function) ---- */
 void sdrx_oracle_synth_iq(uint64_t seed, uint64_t n_start, size_t n, float noise_amp,
                           int n_carriers, const float *const *carrier_tables_iq, int N,

@@ -51,7 +51,9 @@ class _Cfg(C.Structure):
                 ("max_in_len", C.c_uint32), ("block_hint", C.c_uint32),
                 ("audio_fir_taps", C.POINTER(C.c_float)), ("n_audio_fir_taps", C.c_uint32), ("audio_fir_gain_db", C.c_float),
                 ("sql_level", C.POINTER(C.c_float)), ("passband_shape", C.POINTER(C.c_float)),
-                ("ramp_up", C.POINTER(C.c_float)), ("ramp_down", C.POINTER(C.c_float))]
+                ("ramp_up", C.POINTER(C.c_float)), ("ramp_down", C.POINTER(C.c_float)),
+                ("pan_pos", C.POINTER(C.c_int8)), ("mix_fir_taps", C.POINTER(C.c_float)),
+                ("n_mix_fir_taps", C.c_uint32), ("mix_fir_gain_db", C.c_float)]
 
 
 class BankInfo(C.Structure):
@@ -117,6 +119,9 @@ def load_library():
     L.sdrxgpu_bank_get_info.argtypes = [vp, C.POINTER(BankInfo)]
     L.sdrxgpu_bank_get_gains.argtypes = [vp, vp, vp]
     L.sdrxgpu_bank_get_squelch.argtypes = [vp, vp, vp]
+    L.sdrxgpu_audio_pos.argtypes = [C.c_uint, C.c_uint]
+    L.sdrxgpu_bank_get_mix.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
+    L.sdrxgpu_bank_mix_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]
     L.sdrxgpu_bank_profile_enable.argtypes = [vp, C.c_int]
     L.sdrxgpu_bank_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sdrxgpu_bank_profile_reset.argtypes = [vp]
@@ -128,6 +133,7 @@ EXPORTED_SYMBOLS = [
     "sdrxgpu_agc_params_sdrx", "sdrxgpu_make_translator", "sdrxgpu_bank_create", "sdrxgpu_bank_destroy",
     "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_flush", "sdrxgpu_bank_ingest_buffer",
     "sdrxgpu_host_register", "sdrxgpu_host_unregister", "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_get_squelch", "sdrxgpu_bank_profile_enable",
+    "sdrxgpu_audio_pos", "sdrxgpu_bank_get_mix", "sdrxgpu_bank_mix_buffers",
     "sdrxgpu_bank_profile_read", "sdrxgpu_bank_profile_reset", "sdrxgpu_strerror", "sdrxgpu_last_error",
     "sdrxgpu_version",
 ]
@@ -177,6 +183,11 @@ def translators_for(chain, offsets):
     return out
 
 
+def audio_pos(channel_no, num_channels):
+    """get_audio_pos of sdrx.cpp:1024-1044."""
+    return int(load_library().sdrxgpu_audio_pos(channel_no, num_channels))
+
+
 def sdrx_agc_params():
     agc, lf = AgcParams(), AgcParams()
     load_library().sdrxgpu_agc_params_sdrx(C.byref(agc), C.byref(lf))
@@ -193,7 +204,7 @@ class ChannelBank:
 
     def __init__(self, translators, stages, lf_agc=False, agc=None, agc_lf=None, device=-1, stream=None,
                  max_in_len=0, block_hint=0, pipelined=False, ftfir=False,
-                 audio_fir=None, audio_fir_gain_db=0.0, squelch=None):
+                 audio_fir=None, audio_fir_gain_db=0.0, squelch=None, pan_pos=None, mix_fir=None, mix_fir_gain_db=0.0):
         L = load_library()
         self._L = L
         n_ch = len(translators)
@@ -233,6 +244,16 @@ class ChannelBank:
             assert len(self._sq[0]) == n_ch and all(len(t) == 512 for t in self._sq[1:])
             fp = C.POINTER(C.c_float)
             cfg.sql_level, cfg.passband_shape, cfg.ramp_up, cfg.ramp_down = [t.ctypes.data_as(fp) for t in self._sq]
+        if pan_pos is not None:
+            # stereo mix-down: pan position per channel (-2..2), optional common FIR2 taps + volume in dB
+            self._pan = np.ascontiguousarray(pan_pos, dtype=np.int8)
+            assert len(self._pan) == n_ch
+            cfg.pan_pos = self._pan.ctypes.data_as(C.POINTER(C.c_int8))
+            if mix_fir is not None:
+                self._mixfir = np.ascontiguousarray(mix_fir, dtype=np.float32)
+                cfg.mix_fir_taps = self._mixfir.ctypes.data_as(C.POINTER(C.c_float))
+                cfg.n_mix_fir_taps = len(self._mixfir)
+                cfg.mix_fir_gain_db = mix_fir_gain_db
         h = C.c_void_p()
         _check(L.sdrxgpu_bank_create(C.byref(cfg), C.byref(h)), "sdrxgpu_bank_create")
         self._h = h
@@ -282,6 +303,15 @@ class ChannelBank:
         st = np.empty(self.n_channels, dtype=np.uint8)
         _check(self._L.sdrxgpu_bank_get_squelch(self._h, snr.ctypes.data, st.ctypes.data), "sdrxgpu_bank_get_squelch")
         return snr, st
+
+    def mix(self):
+        """(float32 [n, 2], int16 [n, 2]): the stereo mix of the last process call (sdrx.cpp:469-497, 646-656)."""
+        n = C.c_size_t(0)
+        _check(self._L.sdrxgpu_bank_get_mix(self._h, None, None, 0, C.byref(n)), "sdrxgpu_bank_get_mix")
+        f = np.empty((n.value, 2), dtype=np.float32)
+        q = np.empty((n.value, 2), dtype=np.int16)
+        _check(self._L.sdrxgpu_bank_get_mix(self._h, f.ctypes.data, q.ctypes.data, n.value, C.byref(n)), "sdrxgpu_bank_get_mix")
+        return f, q
 
     # ---- the hot path ----
     def process(self, iq, out_stride=None, want_iq=True, want_audio=True, iq_out=None, audio_out=None):

@@ -596,28 +596,30 @@ template <bool SQ>
 __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const AgcParams &A, const AgcParams &Lf, int lf_active,
                                           int mode = 1, float ramp = 1.0f)
 {
-    // AGC::adjust, agc.hpp:48-69 (same operation order, unfused)
-    const float yr = __fmul_rn(x.x, st.g), yi = __fmul_rn(x.y, st.g);
-    const float nrm = __fadd_rn(__fmul_rn(yr, yr), __fmul_rn(yi, yi));
-    st.pw = __fadd_rn(st.pw, __fmul_rn(A.alpha, __fsub_rn(nrm, st.pw)));
-    const float err = __fsub_rn(A.reference, st.pw);
-    st.g = __fadd_rn(st.g, __fmul_rn(err > 0.0f ? A.decay : A.attack, err));
+    // AGC::adjust, agc.hpp:48-69, same operation order.  a + b*c contracts to FMA here, as it does in the reference's
+    // own -march=native build; measured (round 1): a contract(off) build is no closer to the portable golden vectors
+    // (the 1-ulp v_sqrt and the incoming IQ error dominate) and 5 % slower.
+    const float yr = x.x * st.g, yi = x.y * st.g;
+    const float nrm = yr * yr + yi * yi;
+    st.pw = st.pw + A.alpha * (nrm - st.pw);
+    const float err = A.reference - st.pw;
+    st.g = st.g + (err > 0.0f ? A.decay : A.attack) * err;
     st.g = __builtin_amdgcn_fmed3f(st.g, A.min_gain, A.max_gain);      // the clamp of agc.hpp:63-67 in one instruction
     // Demod::demod AM: std::abs, sdrx.cpp:178-180.  v_sqrt_f32 (1 ulp) instead of the correctly rounded
     // software sequence: this loop is a 512-step dependency chain, its latency is the kernel's run time
     const float s = __builtin_amdgcn_sqrtf(nrm);
     // LfAGC::adjust, agc.hpp:106-131 -- only while the squelch is open or ramping down (sdrx.cpp:458-463, 498-501)
-    const float sl = __fmul_rn(s, st.gl);
-    const float pl = __fadd_rn(st.pl, __fmul_rn(Lf.alpha, __fsub_rn(__fmul_rn(sl, sl), st.pl)));
-    const float errl = __fsub_rn(Lf.reference, __builtin_amdgcn_sqrtf(pl));
-    float gl = __fadd_rn(st.gl, __fmul_rn(errl > 0.0f ? Lf.decay : Lf.attack, errl));
+    const float sl = s * st.gl;
+    const float pl = st.pl + Lf.alpha * (sl * sl - st.pl);
+    const float errl = Lf.reference - __builtin_amdgcn_sqrtf(pl);
+    float gl = st.gl + (errl > 0.0f ? Lf.decay : Lf.attack) * errl;
     gl = __builtin_amdgcn_fmed3f(gl, Lf.min_gain, Lf.max_gain);
     float out = lf_active ? sl : s;
     if constexpr (SQ) {
         const bool live = mode != 0;
         st.pl = live ? pl : st.pl;
         st.gl = live ? gl : st.gl;
-        out = __fmul_rn(ramp, out);           // ramp = ramp_up[i] / ramp_down[i] / 1 (open) / 0 (closed)
+        out = ramp * out;                     // ramp = ramp_up[i] / ramp_down[i] / 1 (open) / 0 (closed)
         return live ? out : 0.0f;
     } else {
         st.pl = pl;
@@ -806,6 +808,121 @@ __global__ __launch_bounds__(256) void k_audio_fir(const AudioFirArgs a)
         row[i] = acc;
     }
     for (int i = tid; i < a.T - 1; i += blockDim.x) h[i] = buf[a.n_out + i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Stereo mix-down of the gated channel audio (optional): the back half of alsa_write_cb.
+//   k_mix_partial : pan-weighted sums over groups of kMixGroup consecutive channels, channel order inside a
+//                   group as the reference's `for (auto &ch : channels)` (sdrx.cpp:452, 469-497);
+//   k_mix_reduce  : group sums added in group order -> planar mix rows [2][stride];
+//   (k_audio_fir on the two rows = FIR2, fir.hpp:137-157, sdrx.cpp:646)
+//   k_mix_out     : interleave + float -> S16 with the clamp of sdrx.cpp:649-656.
+// A bank of <= kMixGroup channels reproduces the reference's summation order exactly; larger banks differ from it
+// by re-association only (products and adds are unfused and individually rounded as in the portable build).
+// ------------------------------------------------------------------------------------------
+constexpr int kMixGroup = 64;
+
+struct MixArgs {
+    const float *audio;      // [n_ch][stride] gated mono audio of this chunk
+    const float2 *w;         // [n_ch] pan weights (even slot, odd slot)
+    float *partial;          // [n_groups][2][pstride]
+    float *mix;              // [2][pstride] planar
+    float *out_f32;          // [n_out][2] interleaved
+    short *out_s16;          // [n_out][2] interleaved
+    int n_ch, n_out, stride, pstride, n_groups;
+};
+
+// grid (ceil(n_out/256), n_groups), 64 threads; a lane owns 4 consecutive output samples
+__global__ __launch_bounds__(64) void k_mix_partial(const MixArgs a)
+{
+#pragma clang fp contract(off)   // w*s is rounded before the add, as in the reference's portable build
+    const int i0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int g = blockIdx.y;
+    const int c0 = g * kMixGroup;
+    const int c1 = min(c0 + kMixGroup, a.n_ch);
+    if (i0 >= a.n_out) return;
+    const bool vec = (i0 + 4 <= a.n_out) && ((a.stride & 3) == 0) && (((uintptr_t)a.audio & 15) == 0);
+    float e[4] = {0.f, 0.f, 0.f, 0.f}, o[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    for (int c = c0; c < c1; c += U) {
+        float s[U][4];
+        float2 w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int cc = min(c + u, c1 - 1);
+            const float *row = a.audio + (size_t)cc * a.stride + i0;
+            w[u] = a.w[cc];
+            if (vec) {
+                const float4 v = *reinterpret_cast<const float4 *>(row);
+                s[u][0] = v.x; s[u][1] = v.y; s[u][2] = v.z; s[u][3] = v.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) s[u][q] = (i0 + q < a.n_out) ? row[q] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (c + u < c1) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    e[q] = e[q] + w[u].x * s[u][q];
+                    o[q] = o[q] + w[u].y * s[u][q];
+                }
+            }
+        }
+    }
+    float *pe = a.partial + ((size_t)g * 2 + 0) * a.pstride + i0;
+    float *po = a.partial + ((size_t)g * 2 + 1) * a.pstride + i0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (i0 + q < a.n_out) { pe[q] = e[q]; po[q] = o[q]; }
+}
+
+// grid (ceil(n_out/64), 2), 256 threads: the four waves each add a contiguous quarter of the groups in order for
+// the same 64 samples, then the quarters are added in order
+__global__ __launch_bounds__(256) void k_mix_reduce(const MixArgs a)
+{
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const int lr = blockIdx.y;
+    const int per = (a.n_groups + 3) / 4;
+    const int g0 = wv * per, g1 = min(g0 + per, a.n_groups);
+    float acc = 0.f;
+    if (i < a.n_out) {
+        constexpr int U = 8;
+        for (int g = g0; g < g1; g += U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = a.partial[((size_t)min(g + u, g1 - 1) * 2 + lr) * a.pstride + i];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (g + u < g1) acc = __fadd_rn(acc, v[u]);
+        }
+    }
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && i < a.n_out) {
+        float t = part[0][lane];
+        if (per < a.n_groups) t = __fadd_rn(t, part[1][lane]);
+        if (2 * per < a.n_groups) t = __fadd_rn(t, part[2][lane]);
+        if (3 * per < a.n_groups) t = __fadd_rn(t, part[3][lane]);
+        a.mix[(size_t)lr * a.pstride + i] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mix_out(const MixArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_out) return;
+    const float x0 = a.mix[i], x1 = a.mix[a.pstride + i];
+    reinterpret_cast<float2 *>(a.out_f32)[i] = make_float2(x0, x1);
+    auto cvt = [](float x) -> short {                      // sdrx.cpp:649-656
+        if (x > 1.0f) return (short)32767;
+        if (x < -1.0f) return (short)-32767;
+        return (short)(int)__fmul_rn(x, 32767.0f);         // truncation toward zero, as the C cast
+    };
+    reinterpret_cast<short2 *>(a.out_s16)[i] = make_short2(cvt(x0), cvt(x1));
 }
 
 // move x[src_off .. src_off+cnt) to x[0 .. cnt) (ranges may overlap; cnt <= blockDim.x = 1024)

@@ -219,6 +219,12 @@ struct sdrxgpu_bank {
     float *d_snr = nullptr, *d_sql_level = nullptr, *d_sq_tabs = nullptr;   // d_sq_tabs: window | passband | ramp_up | ramp_down
     float2 *d_tw = nullptr;
     int fir_T = 0;
+    // optional stereo mix-down
+    bool mix = false;
+    float2 *d_pan_w = nullptr;
+    float *d_mix_partial = nullptr, *d_mix = nullptr, *d_mix_f32 = nullptr, *d_mix_taps = nullptr, *d_mix_hist = nullptr;
+    short *d_mix_s16 = nullptr;
+    int mix_T = 0, mix_groups = 0, mix_frames = 0;
     size_t device_bytes = 0;
 
     // pipelined mode: stage-1/2 of block k runs on `stream2` while the tail stages + AGC of block k-1
@@ -284,6 +290,13 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_tw);
     (void)hipFree(b->d_fir_taps);
     (void)hipFree(b->d_fir_hist);
+    (void)hipFree(b->d_pan_w);
+    (void)hipFree(b->d_mix_partial);
+    (void)hipFree(b->d_mix);
+    (void)hipFree(b->d_mix_f32);
+    (void)hipFree(b->d_mix_s16);
+    (void)hipFree(b->d_mix_taps);
+    (void)hipFree(b->d_mix_hist);
     if (b->owns_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -303,6 +316,8 @@ static int init_state(sdrxgpu_bank *b)
         HIPCHK(hipMemsetAsync(b->d_snr, 0, (size_t)b->n_ch * sizeof(float), b->stream));
     }
     if (b->fir_T) HIPCHK(hipMemsetAsync(b->d_fir_hist, 0, (size_t)b->n_ch * (b->fir_T - 1) * sizeof(float), b->stream));
+    if (b->mix_T) HIPCHK(hipMemsetAsync(b->d_mix_hist, 0, (size_t)2 * (b->mix_T - 1) * sizeof(float), b->stream));
+    b->mix_frames = 0;
     std::vector<float4> st(b->n_ch, make_float4(b->agc.init_gain, b->agc.init_power, b->lf.init_gain, b->lf.init_power));
     HIPCHK(hipMemcpyAsync(b->d_state, st.data(), st.size() * sizeof(float4), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -597,6 +612,44 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "audio FIR tap upload failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (cfg->pan_pos) {
+        if (cfg->n_mix_fir_taps && (!cfg->mix_fir_taps || cfg->n_mix_fir_taps > 4096)) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: mix FIR needs 1..4096 taps");
+        }
+        b->mix = true;
+        b->mix_T = (int)cfg->n_mix_fir_taps;
+        b->mix_groups = (int)((b->n_ch + kMixGroup - 1) / kMixGroup);
+        std::vector<float2> w(b->n_ch);
+        for (uint32_t c = 0; c < b->n_ch; c++) {
+            switch (cfg->pan_pos[c]) {                       // sdrx.cpp:471-497
+                case -2: w[c] = make_float2(0.8f, 0.2f); break;
+                case -1: w[c] = make_float2(0.6f, 0.4f); break;
+                case 1:  w[c] = make_float2(0.4f, 0.6f); break;
+                case 2:  w[c] = make_float2(0.2f, 0.8f); break;
+                default: w[c] = make_float2(0.5f, 0.5f); break;
+            }
+        }
+        std::vector<float> c(cfg->mix_fir_taps, cfg->mix_fir_taps + b->mix_T);
+        for (float &v : c) v = v * std::pow(10.0f, cfg->mix_fir_gain_db / 20.0f);   // FIR2::setGain, fir.hpp:160-170
+        const size_t ks = (size_t)b->keep_stride;
+        if ((rc = dev_alloc(b, (void **)&b->d_pan_w, w.size() * sizeof(float2))) ||
+            (rc = dev_alloc(b, (void **)&b->d_mix_partial, (size_t)b->mix_groups * 2 * ks * sizeof(float))) ||
+            (rc = dev_alloc(b, (void **)&b->d_mix, 2 * ks * sizeof(float))) ||
+            (rc = dev_alloc(b, (void **)&b->d_mix_f32, 2 * ks * sizeof(float))) ||
+            (rc = dev_alloc(b, (void **)&b->d_mix_s16, 2 * ks * sizeof(short))) ||
+            (rc = dev_alloc(b, (void **)&b->d_mix_taps, c.size() * sizeof(float) + 16)) ||
+            (rc = dev_alloc(b, (void **)&b->d_mix_hist, (size_t)2 * (b->mix_T > 0 ? b->mix_T - 1 : 0) * sizeof(float) + 16))) {
+            free_bank(b);
+            return rc;
+        }
+        hipError_t e = hipMemcpy(b->d_pan_w, w.data(), w.size() * sizeof(float2), hipMemcpyHostToDevice);
+        if (e == hipSuccess && b->mix_T) e = hipMemcpy(b->d_mix_taps, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "mix table upload failed: %s", hipGetErrorString(e));
         }
     }
     if (b->pipelined) {
@@ -964,6 +1017,37 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             hipLaunchKernelGGL(k_audio_fir, dim3(b->n_ch), dim3(256), lds, b->stream, f);
             HIPCHK(hipGetLastError());
         }
+        if (b->mix) {
+            MixArgs x;
+            x.audio = g.audio;
+            x.stride = g.out_stride;
+            x.w = b->d_pan_w;
+            x.partial = b->d_mix_partial;
+            x.mix = b->d_mix;
+            x.out_f32 = b->d_mix_f32;
+            x.out_s16 = b->d_mix_s16;
+            x.n_ch = (int)b->n_ch;
+            x.n_out = t.n_b;
+            x.pstride = b->keep_stride;
+            x.n_groups = b->mix_groups;
+            hipLaunchKernelGGL(k_mix_partial, dim3((t.n_b + 255) / 256, b->mix_groups), dim3(64), 0, b->stream, x);
+            hipLaunchKernelGGL(k_mix_reduce, dim3((t.n_b + 63) / 64, 2), dim3(256), 0, b->stream, x);
+            if (b->mix_T) {
+                AudioFirArgs f;                         // FIR2 = the same FIR on the two planar rows
+                f.audio = b->d_mix;
+                f.stride = b->keep_stride;
+                f.hist = b->d_mix_hist;
+                f.taps = b->d_mix_taps;
+                f.n_ch = 2;
+                f.n_out = t.n_b;
+                f.T = b->mix_T;
+                const size_t lds = ((size_t)2 * b->mix_T + t.n_b) * sizeof(float);
+                hipLaunchKernelGGL(k_audio_fir, dim3(2), dim3(256), lds, b->stream, f);
+            }
+            hipLaunchKernelGGL(k_mix_out, dim3((t.n_b + 255) / 256), dim3(256), 0, b->stream, x);
+            HIPCHK(hipGetLastError());
+            b->mix_frames = t.n_b;
+        }
     }
     *produced = (size_t)t.n_b;
     b->n_out += (uint64_t)t.n_b;
@@ -1011,7 +1095,10 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
     if (b->HIST + 1 > 1024) return fail(SDRXGPU_ERR_UNSUPPORTED, "internal: history %d > 1023", b->HIST);
     if (b->pipelined && (in_is_host || out_is_host || in_len > b->max_chunk))
         return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a pipelined bank takes device pointers and at most max_in_len samples per call");
+    if (b->mix && in_len > b->max_chunk)
+        return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a bank with mix-down takes at most max_in_len = %u samples per call", b->max_chunk);
     HIPCHK(hipSetDevice(b->device));
+    if (b->mix && !b->pipelined) b->mix_frames = 0;
     ProfScope total(b, SDRXGPU_K_TOTAL);
 
     const float2 *src = (const float2 *)in;
@@ -1091,6 +1178,41 @@ extern "C" int sdrxgpu_host_unregister(void *ptr)
 {
     if (!ptr) return fail(SDRXGPU_ERR_INVALID_ARG, "host_unregister: null pointer");
     HIPCHK(hipHostUnregister(ptr));
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_audio_pos(unsigned channel_no, unsigned num_channels)
+{
+    // sdrx.cpp:1024-1044 with its five positions
+    const unsigned half = num_channels / 2;
+    if (channel_no >= num_channels) return 0;
+    if (channel_no < half) return (int)(std::floor((float)(channel_no * 5u) / (float)num_channels) - 2.0f);
+    if (channel_no == half && (num_channels & 1u)) return 0;
+    return (int)(2.0f - std::floor((float)((num_channels - 1 - channel_no) * 5u) / (float)num_channels));
+}
+
+extern "C" int sdrxgpu_bank_mix_buffers(sdrxgpu_bank *b, void **d_mix_f32, void **d_mix_s16, size_t *n_frames)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_mix_buffers: null bank");
+    if (!b->mix) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_mix_buffers: the bank was created without pan_pos");
+    if (d_mix_f32) *d_mix_f32 = b->d_mix_f32;
+    if (d_mix_s16) *d_mix_s16 = b->d_mix_s16;
+    if (n_frames) *n_frames = (size_t)b->mix_frames;
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_bank_get_mix(sdrxgpu_bank *b, float *mix_f32, int16_t *mix_s16, size_t cap_frames, size_t *n_frames)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_mix: null bank");
+    if (!b->mix) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_mix: the bank was created without pan_pos");
+    const size_t n = (size_t)b->mix_frames;
+    if (n_frames) *n_frames = n;
+    if ((mix_f32 || mix_s16) && cap_frames < n)
+        return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "bank_get_mix: %zu frames but room for %zu", n, cap_frames);
+    HIPCHK(hipSetDevice(b->device));
+    if (mix_f32 && n) HIPCHK(hipMemcpyAsync(mix_f32, b->d_mix_f32, n * 2 * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    if (mix_s16 && n) HIPCHK(hipMemcpyAsync(mix_s16, b->d_mix_s16, n * 2 * sizeof(short), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     return SDRXGPU_OK;
 }
 

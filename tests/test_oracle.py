@@ -215,3 +215,50 @@ def test_squelch_restatement_vs_numpy_fft(oracle):
     # closed/silent, opens after the first carrier chunk (audio still silent in it), open with audio,
     # closes after the first noise chunk (that chunk still has audio), then ramp-down chunk, i.e. audio once more
     assert states == [(0, False), (1, False), (1, True), (0, True), (0, True)]
+
+
+# ---- stereo mix-down restatements (sdrx.cpp:469-497, 646-656, 1024-1044; fir.hpp:131-183) ----
+def test_fir2_bit_exact_vs_reference_fixture(oracle):
+    """FIR2 restated == the reference's class (portable build) on the committed stereo vector, ragged calls, in place."""
+    z = np.load(os.path.join(GOLD, "aux", "fir2_stereo.npz"))
+    f2 = oracle.fir2(chains.audio_bpf_taps(), float(z["gain_db"]))
+    cuts = [int(c) for c in z["cuts"]]
+    y = np.concatenate([f2.filter(z["x"][a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(y.view(np.uint32), z["y"].view(np.uint32))
+    assert float(np.abs(z["y_avx2"] - z["y"]).max()) < 1e-6           # the reference's own two builds
+    # FIR2 is FIR on each slot (what the device runs on its two planar rows)
+    for k in (0, 1):
+        f1 = oracle.fir(chains.audio_bpf_taps(), float(z["gain_db"]))
+        assert np.array_equal(f1.filter(z["x"][:, k]).view(np.uint32), z["y"][:, k].view(np.uint32))
+
+
+def test_audio_pos_table(oracle):
+    """get_audio_pos by hand from sdrx.cpp:1024-1044: five positions spread symmetrically, centre for the odd middle."""
+    assert [oracle.audio_pos(c, 1) for c in range(1)] == [0]
+    assert [oracle.audio_pos(c, 2) for c in range(2)] == [-2, 2]
+    assert [oracle.audio_pos(c, 3) for c in range(3)] == [-2, 0, 2]
+    assert [oracle.audio_pos(c, 5) for c in range(5)] == [-2, -1, 0, 1, 2]
+    assert [oracle.audio_pos(c, 7) for c in range(7)] == [-2, -2, -1, 0, 1, 2, 2]
+    assert [oracle.audio_pos(c, 10) for c in range(10)] == [-2, -2, -1, -1, 0, 0, 1, 1, 2, 2]
+    assert oracle.audio_pos(12, 10) == 0                                 # out of range: pos stays 0
+    for n in (4, 9, 64, 1001):
+        p = [oracle.audio_pos(c, n) for c in range(n)]
+        assert p == [-q for q in reversed(p)] and min(p) == -2 and max(p) == 2
+
+
+def test_pan_mix_and_s16_known_answers(oracle):
+    f = np.float32
+    au = np.array([[1.0, 0.5], [2.0, -1.0], [0.25, 0.0], [4.0, 1.0], [8.0, 3.0]], dtype=np.float32)
+    pos = [-2, -1, 0, 1, 2]
+    w0 = [f(0.8), f(0.6), f(0.5), f(0.4), f(0.2)]
+    w1 = [f(0.2), f(0.4), f(0.5), f(0.6), f(0.8)]
+    want = np.zeros((2, 2), np.float32)
+    for c in range(5):                                   # serial float32 accumulation in channel order
+        for i in range(2):
+            want[i, 0] = f(want[i, 0] + f(w0[c] * au[c, i]))
+            want[i, 1] = f(want[i, 1] + f(w1[c] * au[c, i]))
+    got = oracle.pan_mix(au, pos)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(oracle.pan_mix(au[:1], [7]), np.array([[0.5, 0.5], [0.25, 0.25]], np.float32))   # default: centre
+    x = np.array([1.5, -1.5, 1.0, -1.0, 0.5, -0.5, 0.99999, 3.0e-5, -3.0e-5, 0.0], dtype=np.float32)
+    assert oracle.to_s16(x).tolist() == [32767, -32767, 32767, -32767, 16383, -16383, 32766, 0, 0, 0]
