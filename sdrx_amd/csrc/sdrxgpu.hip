@@ -209,6 +209,7 @@ struct sdrxgpu_bank {
     float2 *d_hist[2] = {nullptr, nullptr};   // stage-2 history, ping-pong between calls
     int hist_cur = 0;
     int tile_b = 64;                          // final outputs per k_tail workgroup (64: 8 workgroups per CU)
+    bool tail_generic = false;                // SDRXGPU_TAIL_GENERIC=1: run-time-tap k_tail even for the compiled-in chains
     size_t tail_lds = 0;
     float *d_audio_keep = nullptr;
     float4 *d_state = nullptr;
@@ -418,6 +419,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
 
     // LDS of one k_tail tile: the stage-2 span of tile_b outputs (+ FIR history) and its stage-A outputs
     if (const char *e = getenv("SDRXGPU_TAIL_TILE")) b->tile_b = std::max(8, std::min(128, atoi(e)));
+    if (const char *e = getenv("SDRXGPU_TAIL_GENERIC")) b->tail_generic = atoi(e) != 0;
     {
         const int tB = (int)b->ntaps[cfg->n_stages - 1], mB = (int)b->m[cfg->n_stages - 1];
         size_t np, nr = 0;
@@ -427,7 +429,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         } else {
             np = (size_t)mB * (b->tile_b - 1) + tB;
         }
-        b->tail_lds = (np + 4 + nr) * sizeof(float2);     // + alignment slack of the 16-byte staging
+        b->tail_lds = (np + 8 + nr) * sizeof(float2);     // + alignment slack of the staging by groups of Y2B
         if (b->tail_lds > 150 * 1024) {
             free_bank(b);
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tail stages need %zu B of LDS per tile (max 153600)", b->tail_lds);
@@ -905,6 +907,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         t.n_b = (int)(q1 - q_prev);
         t.tile_b = b->tile_b;
         t.y2b = k->Y2B;
+        t.y2b_shift = (k->Y2B == 4) ? 2 : 1;
         t.seg_len = b->bps * k->Y2B;
         t.ph_len = b->nb * k->Y2B;
         t.spw = kWave / b->CPW;
@@ -954,7 +957,20 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     t.out_stride = (int)out_stride;
     {
         ProfScope ps(b, SDRXGPU_K_TAIL);
-        hipLaunchKernelGGL(k_tail, dim3(((b->n_ch + 7) / 8 * 8) * t.n_tiles), dim3(256), b->tail_lds, b->stream, t);
+        const dim3 grid(((b->n_ch + 7) / 8 * 8) * t.n_tiles);
+        const int mA = t.has_a ? t.mA : 0, tA = t.has_a ? t.tA : 0;
+        // the tail stages of the reference's chains (sdrx.cpp:1588-1668) are compiled in; anything else runs generic
+#define SDRX_TAIL_CASE(MA_, TA_, MB_, TB_)                                                                       \
+        if (!b->tail_generic && mA == MA_ && tA == TA_ && t.mB == MB_ && t.tB == TB_)                            \
+            hipLaunchKernelGGL((k_tail_s<MA_, TA_, MB_, TB_>), grid, dim3(256), b->tail_lds, b->stream, t);      \
+        else
+        SDRX_TAIL_CASE(5, 21, 5, 67)     // 10 MS/s
+        SDRX_TAIL_CASE(5, 19, 5, 45)     // 2.4 MS/s
+        SDRX_TAIL_CASE(0, 0, 5, 45)      // 0.96 / 1.2 / 1.44 / 1.6 / 1.92 MS/s
+        SDRX_TAIL_CASE(0, 0, 5, 67)      // 6 MS/s
+        SDRX_TAIL_CASE(0, 0, 2, 21)      // 2.56 MS/s
+            hipLaunchKernelGGL(k_tail, grid, dim3(256), b->tail_lds, b->stream, t);
+#undef SDRX_TAIL_CASE
         HIPCHK(hipGetLastError());
     }
     b->hist_cur ^= 1;
