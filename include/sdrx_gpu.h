@@ -96,7 +96,8 @@ typedef struct {
     uint32_t               max_in_len;   /* largest in_len of one call the buffers are sized for;
                                             0 = 32 ms block of this chain's rate * 1 (longer calls
                                             are split internally)                */
-    uint32_t               block_hint;   /* 0 = auto; else bodies per lane of the stage-1/2 kernel */
+    uint32_t               block_hint;   /* 0 = auto; else bodies per lane of the stage-1/2 kernel
+                                            (must divide the bodies per segment; 0xFFFFFFFF = a whole segment) */
     /* Optional audio band-pass on every channel's demodulated envelope: FIR::filter with setGain
      * (src/fir.hpp:79-127; sdrx runs FIR2 with coeff_bp4am_channel, coeffs.hpp:1812, on the mixed stereo
      * sum, sdrx.cpp:646 -- linear, so per-channel mono filtering before the mix is the same thing).

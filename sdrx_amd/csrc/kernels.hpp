@@ -575,14 +575,39 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
 // in time and in the body-major storage), one index computation per group.
 // MA == 0: chains with three stages (no stage A).
 // ------------------------------------------------------------------------------------------
+// acc += x * h[K] on both halves, the tap read from one half of an SGPR pair (op_sel picks the half): two taps per
+// pair instead of the (h, h) pair per tap the compiler would build -- 45 taps of the 10 MS/s tail would otherwise
+// need 90 SGPRs and spill into v_readlane/v_writelane traffic.  The s_nop is the wait state a packed op needs
+// when its source was written by the instruction right before it (hipcc cannot see into the asm).
+template <int K>
+__device__ __forceinline__ void fma_tap(v2f &acc, const v2f x, const v2f hpair)
+{
+    if constexpr ((K & 1) == 0)
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "s"(hpair));
+    else
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "s"(hpair));
+}
+
+template <int T, int I = 0>
+__device__ __forceinline__ void folded_fir_steps(v2f &acc, const v2f *__restrict__ w, const float (&h)[kMaxHalfTaps])
+{
+    constexpr int half = (T - 1) >> 1;
+    if constexpr (I <= half) {
+        const v2f hp = {h[I & ~1], h[(I & ~1) + 1]};
+        if constexpr (I < half)
+            fma_tap<I>(acc, w[I] + w[T - 1 - I], hp);
+        else
+            fma_tap<I>(acc, w[half], hp);
+        folded_fir_steps<T, I + 1>(acc, w, h);
+    }
+}
+
 template <int T>
 __device__ __forceinline__ v2f folded_fir_unrolled(const v2f *__restrict__ w, const float (&h)[kMaxHalfTaps])
 {
-    constexpr int half = (T - 1) >> 1;
     v2f acc = {0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < half; i++) acc = __builtin_elementwise_fma(w[i] + w[T - 1 - i], v2f{h[i], h[i]}, acc);
-    return __builtin_elementwise_fma(w[half], v2f{h[half], h[half]}, acc);
+    folded_fir_steps<T>(acc, w, h);
+    return acc;
 }
 
 // group index (time j, a multiple of Y2B) -> index in the channel's body-major row

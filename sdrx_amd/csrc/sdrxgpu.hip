@@ -482,7 +482,9 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
             free_bank(b);
             return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: stage-1/2 geometry W=%d CPW=%d is not compiled for this chain", b->W, b->CPW);
         }
-        if (cfg->block_hint) {
+        if (cfg->block_hint == 0xFFFFFFFFu) {
+            b->nb = b->bps;                   // whole segment per lane (P == 1)
+        } else if (cfg->block_hint) {
             if (b->bps % cfg->block_hint) {
                 free_bank(b);
                 return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: block_hint %u does not divide %d bodies per segment", cfg->block_hint, b->bps);
