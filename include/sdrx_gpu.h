@@ -215,6 +215,8 @@ int sdrxgpu_bank_get_gains(sdrxgpu_bank *bank, float *agc_gain, float *lf_agc_ga
 #define SDRXGPU_K_TAIL    1
 #define SDRXGPU_K_AGC     2
 #define SDRXGPU_K_TOTAL   3
+/* enable: 0 off; 1 every kernel and the whole call (8 event records per block, ~20 us of stream time at 10 000
+ * channels); 2 only SDRXGPU_K_STAGE12, the dominant kernel (what bench.py keeps on inside its timed region). */
 int sdrxgpu_bank_profile_enable(sdrxgpu_bank *bank, int enable);
 int sdrxgpu_bank_profile_read(sdrxgpu_bank *bank, int kernel, double *total_ms, uint64_t *launches);
 int sdrxgpu_bank_profile_reset(sdrxgpu_bank *bank);

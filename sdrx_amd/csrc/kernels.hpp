@@ -729,6 +729,9 @@ struct AgcArgs {
     // squelch gating (sdrx.cpp:458-503); sql == nullptr: every channel is treated as open
     const uchar2 *sql;       // [n_ch] {state, state_prev} left by the previous chunk
     const float *ramp_up, *ramp_down;   // [512]
+    // input-history roll riding along as one extra block: x[roll_src .. +roll_cnt) -> x[0 ..) (roll_cnt <= 1024; 0: none)
+    float2 *roll_x;
+    int roll_src, roll_cnt;
 };
 
 struct AgcState {
@@ -776,6 +779,23 @@ __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const Ag
 template <bool SQ>
 __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
 {
+    // one extra block rolls the input history to the front of the ring for the next call (k_roll_history's
+    // job; riding along here saves a launch on the critical path): a single wave, all reads before all writes
+    if (a.roll_cnt > 0 && blockIdx.x == gridDim.x - 1) {
+        float2 v[1024 / kWave];
+#pragma unroll
+        for (int k = 0; k < 1024 / kWave; k++) {
+            const int i = threadIdx.x + kWave * k;
+            v[k] = i < a.roll_cnt ? a.roll_x[a.roll_src + i] : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 1024 / kWave; k++) {
+            const int i = threadIdx.x + kWave * k;
+            if (i < a.roll_cnt) a.roll_x[i] = v[k];
+        }
+        return;
+    }
     const int ch = blockIdx.x * kWave + threadIdx.x;
     if (ch >= a.n_ch) return;
     const float2 *__restrict__ row = a.iq + (size_t)ch * a.iq_stride;

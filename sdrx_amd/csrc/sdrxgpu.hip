@@ -237,6 +237,7 @@ struct sdrxgpu_bank {
     struct TailJob {
         bool valid = false;
         TailArgs t;
+        int roll_src = 0, roll_cnt = 0;   // input-history roll left for k_agc to do (serial mode)
     } pending;
     int y2_cur = 0;
 
@@ -245,7 +246,7 @@ struct sdrxgpu_bank {
     long long x_origin = 0;          // absolute sample index held at d_x[0] (same parity as the next call's s0)
 
     // profiling
-    bool prof = false;
+    int prof = 0;                    // 0 off, 1 every kernel + whole call, 2 the stage-1/2 kernel only
     std::vector<ProfSpan> prof_pending;
     std::vector<hipEvent_t> pool;
     double prof_ms[4] = {0, 0, 0, 0};
@@ -752,7 +753,8 @@ struct ProfScope {
     ProfSpan s{};
     bool on;
     hipStream_t st;
-    ProfScope(sdrxgpu_bank *bank, int kernel, hipStream_t stream = nullptr) : b(bank), on(bank->prof), st(stream ? stream : bank->stream)
+    ProfScope(sdrxgpu_bank *bank, int kernel, hipStream_t stream = nullptr)
+        : b(bank), on(bank->prof == 1 || (bank->prof == 2 && kernel == SDRXGPU_K_STAGE12)), st(stream ? stream : bank->stream)
     {
         if (!on) return;
         s.kernel = kernel;
@@ -789,7 +791,7 @@ extern "C" int sdrxgpu_bank_profile_enable(sdrxgpu_bank *b, int enable)
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "profile_enable: null bank");
     prof_collect(b);
-    b->prof = enable != 0;
+    b->prof = (enable == 2) ? 2 : (enable != 0);
     return SDRXGPU_OK;
 }
 
@@ -933,8 +935,17 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         const int src_off = (int)(origin_next - b->x_origin);
         const int cnt = (int)(n1 - origin_next);
         if (src_off < 0) return fail(SDRXGPU_ERR_HIP, "internal: history roll offset %d < 0", src_off);
-        hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(1024), 0, st, b->d_x, src_off, cnt);
-        HIPCHK(hipGetLastError());
+        if (cnt > 1024) return fail(SDRXGPU_ERR_HIP, "internal: history roll of %d samples", cnt);
+        // serial mode: the roll rides along with k_agc of the same chunk (launch_tail), when there is one
+        job->roll_src = src_off;
+        job->roll_cnt = (src_off > 0) ? cnt : 0;
+        if (b->pipelined || !job->valid || job->t.n_b <= 0) {
+            if (job->roll_cnt) {
+                hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(1024), 0, st, b->d_x, src_off, cnt);
+                HIPCHK(hipGetLastError());
+            }
+            job->roll_cnt = 0;
+        }
         b->x_origin = origin_next;
     }
     b->n_in += in_len;
@@ -949,10 +960,16 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     if (!job->valid) return SDRXGPU_OK;
     TailArgs &t = job->t;
     job->valid = false;
+    // a call refused here must still leave the input ring consistent: do the history roll k_agc would have done
+    auto refuse = [&](int code) {
+        if (job->roll_cnt > 0) hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(1024), 0, b->stream, b->d_x, job->roll_src, job->roll_cnt);
+        job->roll_cnt = 0;
+        return code;
+    };
     if (out_off + (size_t)t.n_b > out_stride && (d_iq_out || d_audio_out))
-        return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride);
+        return refuse(fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride));
     if (b->squelch && t.n_b != 512)
-        return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a bank with squelch takes whole 512-output chunks (this call produces %d)", t.n_b);
+        return refuse(fail(SDRXGPU_ERR_UNSUPPORTED, "process: a bank with squelch takes whole 512-output chunks (this call produces %d)", t.n_b));
     t.hist_in = b->d_hist[b->hist_cur];
     t.hist_out = b->d_hist[b->hist_cur ^ 1];
     t.iq_out = d_iq_out ? d_iq_out + out_off : nullptr;
@@ -999,14 +1016,19 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         };
         fill(g.agc, b->agc);
         fill(g.lf, b->lf);
+        g.roll_x = b->d_x;
+        g.roll_src = job->roll_src;
+        g.roll_cnt = job->roll_cnt;
+        job->roll_cnt = 0;
+        const unsigned agc_blocks = (unsigned)((b->n_ch + kWave - 1) / kWave) + (g.roll_cnt > 0 ? 1u : 0u);
         g.sql = b->squelch ? b->d_sql : nullptr;
         g.ramp_up = b->squelch ? b->d_sq_tabs + 1024 : nullptr;      // 16-byte aligned (offsets are multiples of 512 floats)
         g.ramp_down = b->squelch ? b->d_sq_tabs + 1536 : nullptr;
         ProfScope ps(b, SDRXGPU_K_AGC);
         if (b->squelch)
-            hipLaunchKernelGGL(k_agc<true>, dim3((b->n_ch + kWave - 1) / kWave), dim3(kWave), 0, b->stream, g);
+            hipLaunchKernelGGL(k_agc<true>, dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
         else
-            hipLaunchKernelGGL(k_agc<false>, dim3((b->n_ch + kWave - 1) / kWave), dim3(kWave), 0, b->stream, g);
+            hipLaunchKernelGGL(k_agc<false>, dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
         HIPCHK(hipGetLastError());
         if (b->squelch) {
             SquelchArgs q;
