@@ -29,6 +29,7 @@
 //   * stage-2 outputs go to a per-channel scratch row in time order; k_tail picks them up.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace sdrxgpu {
@@ -347,56 +348,77 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
             }
         };
 
-        v2f cx = {0.f, 0.f}, ct = {0.f, 0.f};
-        constexpr bool PREFETCH = (M1 <= 6);
-        v2f fx[PREFETCH ? 2 : 1][M1];  // input samples: region k+1 is fetched while region k is computed
-        v2f ft[M1];                    // translator entries (broadcast reads): fetched one region ahead too,
-                                       // but consumed first, so one buffer is enough
-        load_region(xrow, 0, fx[0], cx);
-        load_region(trow, 0, ft, ct);
+        // The arithmetic of one body.  FIRST = the lane's very first (warm-up) body: its stage-2 outputs are never
+        // stored and only the last C2 stage-1 outputs of the warm-up survive (as the stage-2 delay line), so the
+        // stage-2 FIRs, the first KS stage-1 FIRs and the mixer products only those would have read are left out
+        // (a third of the body for the 10 MS/s chain; 1/13 of all bodies are warm-up).
+        auto run_body = [&](auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            constexpr int KS = FIRST ? ((WU * NY1 - C2 > 0) ? ((WU * NY1 - C2 < NY1) ? WU * NY1 - C2 : NY1) : 0) : 0;
+            constexpr int KM = (KS * M1 - C1 > 0) ? (KS * M1 - C1) / M1 : 0;   // regions whose mixer products nobody reads
+            v2f cx = {0.f, 0.f}, ct = {0.f, 0.f};
+            constexpr bool PREFETCH = (M1 <= 6);
+            v2f fx[PREFETCH ? 2 : 1][M1];  // input samples: region k+1 is fetched while region k is computed
+            v2f ft[M1];                    // translator entries (broadcast reads): fetched one region ahead too,
+                                           // but consumed first, so one buffer is enough
+            load_region(xrow, 0, fx[0], cx);
+            load_region(trow, 0, ft, ct);
 
 #pragma unroll
-        for (int q = 0; q < Y2B; q++) {
-            v2f win2[T2];
+            for (int q = 0; q < Y2B; q++) {
+                v2f win2[T2];
 #pragma unroll
-            for (int i = 0; i < C2; i++) win2[i] = w2c[i];
+                for (int i = 0; i < C2; i++) win2[i] = w2c[i];
 #pragma unroll
-            for (int u = 0; u < M2; u++) {
-                const int k = q * M2 + u;
-                // the scheduling barriers keep the compiler from hoisting all reads of the body
-                // (VGPR blow-up) and fix the software pipeline: mix region k, then fetch region k+1
-                // (LDS latency hides behind the FIR arithmetic), then the FIR of region k
-                __builtin_amdgcn_sched_barrier(0);
-                v2f win[T1];
+                for (int u = 0; u < M2; u++) {
+                    const int k = q * M2 + u;
+                    // the scheduling barriers keep the compiler from hoisting all reads of the body
+                    // (VGPR blow-up) and fix the software pipeline: mix region k, then fetch region k+1
+                    // (LDS latency hides behind the FIR arithmetic), then the FIR of region k
+                    __builtin_amdgcn_sched_barrier(0);
+                    v2f win[T1];
 #pragma unroll
-                for (int i = 0; i < C1; i++) win[i] = w1c[i];
-                if constexpr (M1 == 5) {
-                    cmul5_pk(fx[k & 1], ft, &win[C1]);
-                } else {
+                    for (int i = 0; i < C1; i++) win[i] = w1c[i];
+                    if (k >= KM) {
+                        if constexpr (M1 == 5) {
+                            cmul5_pk(fx[k & 1], ft, &win[C1]);
+                        } else {
 #pragma unroll
-                    for (int e = 0; e < M1; e++) win[C1 + e] = cmul_pk(fx[PREFETCH ? (k & 1) : 0][e], ft[e]);
+                            for (int e = 0; e < M1; e++) win[C1 + e] = cmul_pk(fx[PREFETCH ? (k & 1) : 0][e], ft[e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < M1; e++) asm volatile("" : "+v"(win[C1 + e]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < M1; e++) win[C1 + e] = v2f{0.f, 0.f};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 1 < NY1) {
+                        load_region(xrow, k + 1, fx[PREFETCH ? ((k + 1) & 1) : 0], cx);
+                        load_region(trow, k + 1, ft, ct);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k >= KS) {
+                        win2[C2 + u] = folded_fir_pk<T1>(win, taps.h1);
+                        // pin the stage-1 output here: without it LLVM sinks the arithmetic down to the
+                        // stage-2 FIR and every LDS read of the body stays live (spills)
+                        asm volatile("" : "+v"(win2[C2 + u]));
+                    } else {
+                        win2[C2 + u] = v2f{0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int i = 0; i < C1; i++) w1c[i] = win[i + M1];
+                }
+                if constexpr (!FIRST) {
+                    y2v[q] = folded_fir_pk<T2>(win2, taps.h2);
+                    asm volatile("" : "+v"(y2v[q]));
                 }
 #pragma unroll
-                for (int e = 0; e < M1; e++) asm volatile("" : "+v"(win[C1 + e]));
-                __builtin_amdgcn_sched_barrier(0);
-                if (k + 1 < NY1) {
-                    load_region(xrow, k + 1, fx[PREFETCH ? ((k + 1) & 1) : 0], cx);
-                    load_region(trow, k + 1, ft, ct);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                win2[C2 + u] = folded_fir_pk<T1>(win, taps.h1);
-                // pin the stage-1 output here: without it LLVM sinks the arithmetic down to the
-                // stage-2 FIR and every LDS read of the body stays live (spills)
-                asm volatile("" : "+v"(win2[C2 + u]));
-#pragma unroll
-                for (int i = 0; i < C1; i++) w1c[i] = win[i + M1];
+                for (int i = 0; i < C2; i++) w2c[i] = win2[i + M2];
             }
-            y2v[q] = folded_fir_pk<T2>(win2, taps.h2);
-            asm volatile("" : "+v"(y2v[q]));
-#pragma unroll
-            for (int i = 0; i < C2; i++) w2c[i] = win2[i + M2];
-        }
-
+        };
+        if (b == 0) run_body(std::true_type{});
+        else run_body(std::false_type{});
     }
     store_y2(a.nb - 1);   // the last body's outputs
 }
