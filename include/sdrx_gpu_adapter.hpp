@@ -24,6 +24,10 @@
 //   * a copy of an MSD (Channel assignment, DS's internal copy) is the SAME channel, not a second
 //     delay line;
 //   * use_ftfir (EXPERIMENTAL in the reference, sdrx.cpp:1199) maps to SDRXGPU_FLAG_FTFIR.
+// Optional (one line in main): sdrxgpu::chunk_stride() = CH_IQ_BUF_SIZE promises that the output pointers of one
+// block are base + channel_index * stride -- what data_cb does with a ring chunk (iq_buf_ptr += CH_IQ_BUF_SIZE,
+// sdrx.cpp:338/344).  The GPU pass then lands directly in the chunk (CRB memory, crb.hpp:110) and the per-channel
+// calls copy nothing.
 #ifndef SDRX_GPU_ADAPTER_HPP
 #define SDRX_GPU_ADAPTER_HPP
 
@@ -48,6 +52,13 @@ inline std::string &last_error()
     return e;
 }
 
+// 0 (default): every decimate()/addJob() copies its channel's row to `out`.  S > 0: see the header comment.
+inline size_t &chunk_stride()
+{
+    static size_t v = 0;
+    return v;
+}
+
 namespace detail {
 
 struct StageCfg {
@@ -70,6 +81,7 @@ struct Group {
     std::vector<iqsample_t> iq;      // [n_ch][stride]
     std::vector<float> audio;        // [n_ch][stride]
     size_t stride = 0, out_len = 0;
+    iqsample_t *direct_base = nullptr;   // chunk the current block was written into (chunk_stride() mode)
     std::vector<uint64_t> consumed;  // per channel: number of blocks taken
     uint64_t produced = 0;           // number of blocks computed
     std::mutex mu;
@@ -123,20 +135,29 @@ struct Group {
         if (consumed[c] == produced) {
             // first caller of a new block: one batched pass for everybody
             const size_t need = in_len / m_total + 1;
-            if (need > stride) {
-                stride = need;
-                iq.assign(translators.size() * stride, iqsample_t(0.0f, 0.0f));
+            const size_t S = chunk_stride();
+            const bool direct = S > 0 && out != nullptr && in_len / m_total <= S;
+            const size_t want = direct ? S : need;
+            if (direct ? stride != S : need > stride) {
+                stride = want;
+                iq.assign(direct ? 0 : translators.size() * stride, iqsample_t(0.0f, 0.0f));
                 audio.assign(translators.size() * stride, 0.0f);
             }
+            if (!direct && iq.size() < translators.size() * stride) iq.assign(translators.size() * stride, iqsample_t(0.0f, 0.0f));
+            direct_base = direct ? out - c * S : nullptr;
+            iqsample_t *dst = direct ? direct_base : iq.data();
             out_len = 0;
             if (!failed) {
                 int rc = sdrxgpu_bank_process(bank, reinterpret_cast<const sdrxgpu_iq *>(in), in_len,
-                                              reinterpret_cast<sdrxgpu_iq *>(iq.data()), audio.data(), stride, &out_len);
+                                              reinterpret_cast<sdrxgpu_iq *>(dst), audio.data(), stride, &out_len);
                 if (rc != SDRXGPU_OK) fail(std::string("sdrxgpu_bank_process: ") + sdrxgpu_strerror(rc));
             }
             if (failed) {
                 out_len = in_len / m_total;
-                std::fill(iq.begin(), iq.end(), iqsample_t(0.0f, 0.0f));
+                if (direct)
+                    for (size_t k = 0; k < translators.size(); k++) std::fill(dst + k * stride, dst + k * stride + out_len, iqsample_t(0.0f, 0.0f));
+                else
+                    std::fill(iq.begin(), iq.end(), iqsample_t(0.0f, 0.0f));
                 std::fill(audio.begin(), audio.end(), 0.0f);
             }
             produced++;
@@ -146,7 +167,21 @@ struct Group {
             std::cerr << "Error: sdrxgpu: " << last_error() << std::endl;
         }
         consumed[c] = produced;
-        if (out) std::memcpy(static_cast<void *>(out), iq.data() + c * stride, out_len * sizeof(iqsample_t));
+        if (direct_base && out && out != direct_base + c * stride) {
+            // the promise of chunk_stride() does not hold: take a private copy of every row of this block before
+            // anything is moved (rows may overlap the places the caller really wants them), serve the rest of the
+            // block from it and go back to copying for good
+            iq.resize(translators.size() * stride);
+            for (size_t k = 0; k < translators.size(); k++)
+                std::memcpy(static_cast<void *>(iq.data() + k * stride), direct_base + k * stride, out_len * sizeof(iqsample_t));
+            direct_base = nullptr;
+            chunk_stride() = 0;
+            if (last_error().empty()) {
+                last_error() = "chunk_stride(): an output pointer is not base + channel * stride; copying from now on";
+                std::cerr << "Error: sdrxgpu: " << last_error() << std::endl;
+            }
+        }
+        if (!direct_base && out) std::memcpy(static_cast<void *>(out), iq.data() + c * stride, out_len * sizeof(iqsample_t));
         if (audio_out) std::memcpy(audio_out, audio.data() + c * stride, out_len * sizeof(float));
         if (out_len_ptr) *out_len_ptr = out_len;
     }
