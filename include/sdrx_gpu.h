@@ -46,6 +46,8 @@ extern "C" {
 #define SDRXGPU_ERR_OUT_TOO_SMALL -6   /* out_stride smaller than the outputs this call produces  */
 
 /* flags */
+#define SDRXGPU_MOD_AM 0
+#define SDRXGPU_MOD_FM 1
 #define SDRXGPU_FLAG_LF_AGC_ACTIVE 0x1u  /* --lf-agc: LfAGC::activate(), sdrx.cpp:1710 */
 #define SDRXGPU_FLAG_FTFIR         0x4u  /* --ftfir (EXPERIMENTAL in the reference, sdrx.cpp:1199): MSD's use_ftfir, msd.hpp:104-131 */
 #define SDRXGPU_FLAG_PIPELINED     0x2u  /* throughput mode for sdrxgpu_bank_process_device only: call k launches the
@@ -127,6 +129,10 @@ typedef struct {
     const float           *mix_fir_taps;
     uint32_t               n_mix_fir_taps;
     float                  mix_fir_gain_db;
+    /* Optional per-channel modulation (Channel::mod, sdrx.cpp:230; --modulation / "ch/sql/FM", EXPERIMENTAL in the
+     * reference): NULL = every channel AM.  SDRXGPU_MOD_FM channels get Demod::demod's FM branch (sdrx.cpp:181-194)
+     * in place of std::abs: audio = atan2 of the phase step between consecutive amplitude-normalised AGC outputs. */
+    const uint8_t         *modulation;
 } sdrxgpu_bank_cfg;
 
 typedef struct {

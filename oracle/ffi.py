@@ -106,6 +106,16 @@ class _Lib:
         self._fn["demod_am"](_fp(iq.view(np.float32)), iq.shape[0], _fp(out))
         return out
 
+    def demod_fm(self, prev, iq):
+        """Demod FM branch; prev = float32[2] state (updated in place)."""
+        assert self.prefix == "sdrx_oracle"
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        out = np.empty(iq.shape[0], dtype=np.float32)
+        self.lib.sdrx_oracle_demod_fm.argtypes = [_f32p, _f32p, C.c_size_t, _f32p]
+        self.lib.sdrx_oracle_demod_fm.restype = None
+        self.lib.sdrx_oracle_demod_fm(_fp(prev), _fp(iq.view(np.float32)), iq.shape[0], _fp(out))
+        return out
+
     def fir(self, taps, gain_db=None):
         return _FIR(self, taps, gain_db)
 
@@ -293,19 +303,22 @@ class _Bank:
 
 class _ChannelStruct(C.Structure):
     _fields_ = [("agc", _AGCStruct), ("agc_lf", _AGCStruct), ("sql_level", C.c_float),
-                ("sql_state", C.c_int), ("sql_state_prev", C.c_int), ("snr", C.c_float)]
+                ("sql_state", C.c_int), ("sql_state_prev", C.c_int), ("snr", C.c_float),
+                ("fm", C.c_int), ("fm_prev", C.c_float * 2)]
 
 
 class SquelchChannel:
     """One channel of alsa_write_cb (sdrx.cpp:455-573): squelch-gated audio + squelch update per 512-sample chunk."""
 
-    def __init__(self, lib, sql_level, window, passband_shape, ramp_up, ramp_down, use_lf_agc=False):
+    def __init__(self, lib, sql_level, window, passband_shape, ramp_up, ramp_down, use_lf_agc=False, fm=False):
         assert lib.prefix == "sdrx_oracle"
         self.L = lib.lib
         self.c = _ChannelStruct()
+        self._fm = fm
         self.L.sdrx_oracle_channel_init.argtypes = [C.POINTER(_ChannelStruct), C.c_float, C.c_int]
         self.L.sdrx_oracle_channel_chunk.argtypes = [C.POINTER(_ChannelStruct), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
         self.L.sdrx_oracle_channel_init(C.byref(self.c), sql_level, int(use_lf_agc))
+        self.c.fm = int(fm)
         self.tabs = [np.ascontiguousarray(t, dtype=np.float32) for t in (window, passband_shape, ramp_up, ramp_down)]
 
     def chunk(self, iq):

@@ -407,6 +407,21 @@ void sdrx_oracle_demod_am(const float *in_iq, size_t n, float *out)
     for (size_t i = 0; i < n; i++) out[i] = cabsf(in_iq[2 * i] + in_iq[2 * i + 1] * I);
 }
 
+/* Demod::demod, FM branch, sdrx.cpp:181-194. */
+void sdrx_oracle_demod_fm(float *prev, const float *in_iq, size_t n, float *out)
+{
+    for (size_t k = 0; k < n; k++) {
+        float complex sample = in_iq[2 * k] + in_iq[2 * k + 1] * I;
+        /* sample = sample / std::abs(sample): complex<float> / float divides both parts (sdrx.cpp:185) */
+        const float mag = cabsf(sample);
+        const float i = crealf(sample) / mag;
+        const float q = cimagf(sample) / mag;
+        out[k] = atan2f(q * prev[0] - i * prev[1], i * prev[0] + q * prev[1]);   /* sdrx.cpp:190 */
+        prev[0] = i;                                                             /* sdrx.cpp:192 */
+        prev[1] = q;
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* FIR, reference src/fir.hpp:79-127 (mono float direct form with dB gain).   */
 /* ------------------------------------------------------------------------- */
@@ -660,6 +675,8 @@ void sdrx_oracle_channel_init(sdrx_oracle_channel *c, float sql_level, int use_l
     c->sql_state = 0;              /* Channel ctor, sdrx.cpp:210 */
     c->sql_state_prev = 0;
     c->snr = 0.0f;
+    c->fm = 0;
+    c->fm_prev[0] = c->fm_prev[1] = 0.0f;
 }
 
 /* sdrx.cpp:533 (fft_in = iq * window), 538 (forward DFT, FFTW_FORWARD = exp(-j...)), 541-567 */
@@ -718,7 +735,8 @@ void sdrx_oracle_channel_chunk(sdrx_oracle_channel *c, const float *iq, const fl
         sdrx_oracle_agc_adjust(&c->agc, iq + 2 * i, 1, y);                 /* always, sdrx.cpp:457 */
         float s = 0.0f;
         if (c->sql_state == 1) {                                           /* sdrx.cpp:458-468 */
-            sdrx_oracle_demod_am(y, 1, &s);
+            if (c->fm) sdrx_oracle_demod_fm(c->fm_prev, y, 1, &s);             /* ch.demod.demod(), sdrx.cpp:461 */
+            else       sdrx_oracle_demod_am(y, 1, &s);
             sdrx_oracle_lfagc_adjust(&c->agc_lf, &s, 1, &s);
             if (c->sql_state_prev == 0) s = ramp_up[i] * s;
         } else if (c->sql_state_prev == 1) {                               /* sdrx.cpp:498-502 */

@@ -60,6 +60,10 @@ void  sdrx_oracle_lfagc_adjust(sdrx_oracle_agc *a, const float *in, size_t n, fl
 
 /* ---- AM demodulator (reference src/sdrx.cpp:178-180) ---- */
 void  sdrx_oracle_demod_am(const float *in_iq, size_t n, float *out);
+/* ---- FM demodulator (EXPERIMENTAL in the reference, src/sdrx.cpp:181-194): phase step between consecutive
+ *      amplitude-normalised samples; prev[2] = Demod::prev_sample, (0, 0) after construction (sdrx.cpp:175).
+ *      Restated from text (Demod lives inside the unbuildable sdrx.cpp): PARITY UNPINNED. ---- */
+void  sdrx_oracle_demod_fm(float *prev, const float *in_iq, size_t n, float *out);
 
 /* ---- FIR (reference src/fir.hpp:79-127) ---- */
 typedef struct sdrx_oracle_fir sdrx_oracle_fir;
@@ -94,6 +98,8 @@ typedef struct {
     float sql_level;
     int   sql_state, sql_state_prev;     /* 0 = SQL_CLOSED, 1 = SQL_OPEN (sdrx.cpp:149) */
     float snr;                           /* last SNR in dB */
+    int   fm;                            /* Channel::mod: 0 = AM (default), 1 = FM (sdrx.cpp:230) */
+    float fm_prev[2];                    /* Demod::prev_sample */
 } sdrx_oracle_channel;
 
 void  sdrx_oracle_hamming_window(float *w /* 512 */);

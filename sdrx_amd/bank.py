@@ -53,7 +53,8 @@ class _Cfg(C.Structure):
                 ("sql_level", C.POINTER(C.c_float)), ("passband_shape", C.POINTER(C.c_float)),
                 ("ramp_up", C.POINTER(C.c_float)), ("ramp_down", C.POINTER(C.c_float)),
                 ("pan_pos", C.POINTER(C.c_int8)), ("mix_fir_taps", C.POINTER(C.c_float)),
-                ("n_mix_fir_taps", C.c_uint32), ("mix_fir_gain_db", C.c_float)]
+                ("n_mix_fir_taps", C.c_uint32), ("mix_fir_gain_db", C.c_float),
+                ("modulation", C.POINTER(C.c_uint8))]
 
 
 class BankInfo(C.Structure):
@@ -204,7 +205,8 @@ class ChannelBank:
 
     def __init__(self, translators, stages, lf_agc=False, agc=None, agc_lf=None, device=-1, stream=None,
                  max_in_len=0, block_hint=0, pipelined=False, ftfir=False,
-                 audio_fir=None, audio_fir_gain_db=0.0, squelch=None, pan_pos=None, mix_fir=None, mix_fir_gain_db=0.0):
+                 audio_fir=None, audio_fir_gain_db=0.0, squelch=None, pan_pos=None, mix_fir=None, mix_fir_gain_db=0.0,
+                 modulation=None):
         L = load_library()
         self._L = L
         n_ch = len(translators)
@@ -244,6 +246,11 @@ class ChannelBank:
             assert len(self._sq[0]) == n_ch and all(len(t) == 512 for t in self._sq[1:])
             fp = C.POINTER(C.c_float)
             cfg.sql_level, cfg.passband_shape, cfg.ramp_up, cfg.ramp_down = [t.ctypes.data_as(fp) for t in self._sq]
+        if modulation is not None:
+            # per channel: 0 / "AM", 1 / "FM"
+            self._mod = np.ascontiguousarray([{"AM": 0, "FM": 1}.get(m_, m_) for m_ in modulation], dtype=np.uint8)
+            assert len(self._mod) == n_ch
+            cfg.modulation = self._mod.ctypes.data_as(C.POINTER(C.c_uint8))
         if pan_pos is not None:
             # stereo mix-down: pan position per channel (-2..2), optional common FIR2 taps + volume in dB
             self._pan = np.ascontiguousarray(pan_pos, dtype=np.int8)

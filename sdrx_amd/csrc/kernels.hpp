@@ -751,6 +751,9 @@ struct AgcArgs {
     // squelch gating (sdrx.cpp:458-503); sql == nullptr: every channel is treated as open
     const uchar2 *sql;       // [n_ch] {state, state_prev} left by the previous chunk
     const float *ramp_up, *ramp_down;   // [512]
+    // per-channel modulation (k_agc<.., true> only): fm[c] != 0 -> FM demodulator, fm_prev = Demod::prev_sample
+    const unsigned char *fm;
+    float2 *fm_prev;
     // input-history roll riding along as one extra block: x[roll_src .. +roll_cnt) -> x[0 ..) (roll_cnt <= 1024; 0: none)
     float2 *roll_x;
     int roll_src, roll_cnt;
@@ -762,9 +765,9 @@ struct AgcState {
 
 // mode: 0 = squelch closed (IF AGC only, silence), 1 = open, 2 = just opened (ramp_up), 3 = just closed (ramp_down).
 // Branch-free: this is a 512-step dependency chain, a branch per step would sit on its critical path.
-template <bool SQ>
+template <bool SQ, bool FM = false>
 __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const AgcParams &A, const AgcParams &Lf, int lf_active,
-                                          int mode = 1, float ramp = 1.0f)
+                                          int mode = 1, float ramp = 1.0f, bool is_fm = false, float2 *fm_prev = nullptr)
 {
     // AGC::adjust, agc.hpp:48-69, same operation order.  a + b*c contracts to FMA here, as it does in the reference's
     // own -march=native build; measured (round 1): a contract(off) build is no closer to the portable golden vectors
@@ -777,7 +780,19 @@ __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const Ag
     st.g = __builtin_amdgcn_fmed3f(st.g, A.min_gain, A.max_gain);      // the clamp of agc.hpp:63-67 in one instruction
     // Demod::demod AM: std::abs, sdrx.cpp:178-180.  v_sqrt_f32 (1 ulp) instead of the correctly rounded
     // software sequence: this loop is a 512-step dependency chain, its latency is the kernel's run time
-    const float s = __builtin_amdgcn_sqrtf(nrm);
+    float s = __builtin_amdgcn_sqrtf(nrm);
+    if constexpr (FM) {
+        // Demod::demod FM (EXPERIMENTAL in the reference, sdrx.cpp:181-194): phase step between consecutive
+        // amplitude-normalised samples.  Called only while the squelch is open (sdrx.cpp:458-461); the ramp-down
+        // chunk takes std::abs whatever the modulation (sdrx.cpp:499).  AM lanes of the same wave compute it too and
+        // drop it (no divergence in the 512-step chain).
+        const float i = yr / s, q = yi / s;                                 // complex<float> / float, sdrx.cpp:185
+        const float ph = atan2f(q * fm_prev->x - i * fm_prev->y, i * fm_prev->x + q * fm_prev->y);
+        const bool use = is_fm && (!SQ || mode == 1 || mode == 2);
+        fm_prev->x = use ? i : fm_prev->x;
+        fm_prev->y = use ? q : fm_prev->y;
+        s = use ? ph : s;
+    }
     // LfAGC::adjust, agc.hpp:106-131 -- only while the squelch is open or ramping down (sdrx.cpp:458-463, 498-501)
     const float sl = s * st.gl;
     const float pl = st.pl + Lf.alpha * (sl * sl - st.pl);
@@ -798,7 +813,7 @@ __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const Ag
     }
 }
 
-template <bool SQ>
+template <bool SQ, bool FM>
 __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
 {
     // one extra block rolls the input history to the front of the ring for the next call (k_roll_history's
@@ -824,6 +839,12 @@ __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
     float *__restrict__ out = a.audio + (size_t)ch * a.out_stride;
     const float4 s4 = a.state[ch];
     AgcState st = {s4.x, s4.y, s4.z, s4.w};
+    bool is_fm = false;
+    float2 fmp = make_float2(0.f, 0.f);
+    if constexpr (FM) {
+        is_fm = a.fm[ch] != 0;
+        fmp = a.fm_prev[ch];
+    }
     int mode = 1;
     const float *__restrict__ ramp = a.ramp_down;
     if constexpr (SQ) {
@@ -867,8 +888,8 @@ __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
         float y[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            y[2 * k + 0] = agc_step<SQ>(make_float2(cur[k].x, cur[k].y), st, a.agc, a.lf, a.lf_active, mode, r[2 * k]);
-            y[2 * k + 1] = agc_step<SQ>(make_float2(cur[k].z, cur[k].w), st, a.agc, a.lf, a.lf_active, mode, r[2 * k + 1]);
+            y[2 * k + 0] = agc_step<SQ, FM>(make_float2(cur[k].x, cur[k].y), st, a.agc, a.lf, a.lf_active, mode, r[2 * k], is_fm, &fmp);
+            y[2 * k + 1] = agc_step<SQ, FM>(make_float2(cur[k].z, cur[k].w), st, a.agc, a.lf, a.lf_active, mode, r[2 * k + 1], is_fm, &fmp);
         }
         if (a.audio_vec) {
             reinterpret_cast<float4 *>(out + base)[0] = make_float4(y[0], y[1], y[2], y[3]);
@@ -878,8 +899,9 @@ __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
             for (int k = 0; k < 8; k++) out[base + k] = y[k];
         }
     }
-    for (int i = n8; i < a.n_out; i++) out[i] = agc_step<SQ>(row[i], st, a.agc, a.lf, a.lf_active, mode, ramped ? ramp[i & 511] : 1.0f);
+    for (int i = n8; i < a.n_out; i++) out[i] = agc_step<SQ, FM>(row[i], st, a.agc, a.lf, a.lf_active, mode, ramped ? ramp[i & 511] : 1.0f, is_fm, &fmp);
     a.state[ch] = make_float4(st.g, st.pw, st.gl, st.pl);
+    if constexpr (FM) a.fm_prev[ch] = fmp;
 }
 
 // ------------------------------------------------------------------------------------------

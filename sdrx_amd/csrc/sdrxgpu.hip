@@ -220,6 +220,9 @@ struct sdrxgpu_bank {
     float *d_snr = nullptr, *d_sql_level = nullptr, *d_sq_tabs = nullptr;   // d_sq_tabs: window | passband | ramp_up | ramp_down
     float2 *d_tw = nullptr;
     int fir_T = 0;
+    // optional per-channel FM demodulation
+    unsigned char *d_fm = nullptr;
+    float2 *d_fm_prev = nullptr;
     // optional stereo mix-down
     bool mix = false;
     float2 *d_pan_w = nullptr;
@@ -292,6 +295,8 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_tw);
     (void)hipFree(b->d_fir_taps);
     (void)hipFree(b->d_fir_hist);
+    (void)hipFree(b->d_fm);
+    (void)hipFree(b->d_fm_prev);
     (void)hipFree(b->d_pan_w);
     (void)hipFree(b->d_mix_partial);
     (void)hipFree(b->d_mix);
@@ -318,6 +323,7 @@ static int init_state(sdrxgpu_bank *b)
         HIPCHK(hipMemsetAsync(b->d_snr, 0, (size_t)b->n_ch * sizeof(float), b->stream));
     }
     if (b->fir_T) HIPCHK(hipMemsetAsync(b->d_fir_hist, 0, (size_t)b->n_ch * (b->fir_T - 1) * sizeof(float), b->stream));
+    if (b->d_fm_prev) HIPCHK(hipMemsetAsync(b->d_fm_prev, 0, (size_t)b->n_ch * sizeof(float2), b->stream));   // prev_sample(0, 0), sdrx.cpp:175
     if (b->mix_T) HIPCHK(hipMemsetAsync(b->d_mix_hist, 0, (size_t)2 * (b->mix_T - 1) * sizeof(float), b->stream));
     b->mix_frames = 0;
     std::vector<float4> st(b->n_ch, make_float4(b->agc.init_gain, b->agc.init_power, b->lf.init_gain, b->lf.init_power));
@@ -617,6 +623,27 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "audio FIR tap upload failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (cfg->modulation) {
+        bool any_fm = false;
+        for (uint32_t c = 0; c < b->n_ch; c++) {
+            if (cfg->modulation[c] > SDRXGPU_MOD_FM) {
+                free_bank(b);
+                return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: modulation[%u] = %u (0 = AM, 1 = FM)", c, cfg->modulation[c]);
+            }
+            any_fm = any_fm || cfg->modulation[c] == SDRXGPU_MOD_FM;
+        }
+        if (any_fm) {       // a bank of AM channels only keeps the AM-only kernel
+            if ((rc = dev_alloc(b, (void **)&b->d_fm, b->n_ch)) || (rc = dev_alloc(b, (void **)&b->d_fm_prev, (size_t)b->n_ch * sizeof(float2)))) {
+                free_bank(b);
+                return rc;
+            }
+            hipError_t e = hipMemcpy(b->d_fm, cfg->modulation, b->n_ch, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                free_bank(b);
+                return fail(SDRXGPU_ERR_HIP, "modulation upload failed: %s", hipGetErrorString(e));
+            }
         }
     }
     if (cfg->pan_pos) {
@@ -1016,6 +1043,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         };
         fill(g.agc, b->agc);
         fill(g.lf, b->lf);
+        g.fm = b->d_fm;
+        g.fm_prev = b->d_fm_prev;
         g.roll_x = b->d_x;
         g.roll_src = job->roll_src;
         g.roll_cnt = job->roll_cnt;
@@ -1026,9 +1055,14 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         g.ramp_down = b->squelch ? b->d_sq_tabs + 1536 : nullptr;
         ProfScope ps(b, SDRXGPU_K_AGC);
         if (b->squelch)
-            hipLaunchKernelGGL(k_agc<true>, dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
+            if (b->d_fm)
+                hipLaunchKernelGGL((k_agc<true, true>), dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
+            else
+                hipLaunchKernelGGL((k_agc<true, false>), dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
+        else if (b->d_fm)
+            hipLaunchKernelGGL((k_agc<false, true>), dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
         else
-            hipLaunchKernelGGL(k_agc<false>, dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
+            hipLaunchKernelGGL((k_agc<false, false>), dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
         HIPCHK(hipGetLastError());
         if (b->squelch) {
             SquelchArgs q;

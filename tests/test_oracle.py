@@ -262,3 +262,19 @@ def test_pan_mix_and_s16_known_answers(oracle):
     assert np.array_equal(oracle.pan_mix(au[:1], [7]), np.array([[0.5, 0.5], [0.25, 0.25]], np.float32))   # default: centre
     x = np.array([1.5, -1.5, 1.0, -1.0, 0.5, -0.5, 0.99999, 3.0e-5, -3.0e-5, 0.0], dtype=np.float32)
     assert oracle.to_s16(x).tolist() == [32767, -32767, 32767, -32767, 16383, -16383, 32766, 0, 0, 0]
+
+
+def test_fm_demod_restatement_vs_float64(oracle):
+    """Demod FM branch (sdrx.cpp:181-194): phase step of consecutive normalised samples; first output is
+    atan2(0, 0) = 0 with prev_sample = (0, 0) (sdrx.cpp:175); the state carries across calls."""
+    rng = np.random.default_rng(0)
+    n = 2000
+    ph = np.cumsum(rng.uniform(-0.5, 0.5, n))
+    x = (rng.uniform(0.5, 2.0, n) * np.exp(1j * ph)).astype(np.complex64)
+    prev = np.zeros(2, np.float32)
+    y = np.concatenate([oracle.demod_fm(prev, x[:777]), oracle.demod_fm(prev, x[777:])])
+    want = np.angle(x[1:].astype(np.complex128) * np.conj(x[:-1].astype(np.complex128)))
+    assert y[0] == 0.0
+    assert float(np.abs(y[1:] - want).max()) < 5e-7
+    xn = x[-1].astype(np.complex128) / abs(x[-1].astype(np.complex128))
+    assert abs(prev[0] - xn.real) < 1e-6 and abs(prev[1] - xn.imag) < 1e-6
