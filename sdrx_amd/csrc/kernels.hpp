@@ -695,21 +695,29 @@ __global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
     v2f *s2 = reinterpret_cast<v2f *>(smem) + lead;             // sample i of the span
     v2f *s3 = reinterpret_cast<v2f *>(smem) + (ngrp << gsh);    // stage-A outputs, after the span
     const int n_row = a.hist + a.n_y2_new;
-    const int halfG = G >> 1;                                    // 16-byte pieces per group
-    for (int i = tid; i < ngrp; i += 256) {
-        const int p = p0g + (i << gsh);
-        const float2 *src = p < a.hist ? hin + p : ynew + y2_group_index(a, p - a.hist);
-        // the last group may reach past the data: entries >= n_row are never used by a FIR window, only staged
-        const bool whole = p + G <= n_row;
-        for (int k = 0; k < halfG; k++) {
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (whole) {
-                v = *reinterpret_cast<const v4f *>(src + 2 * k);
-            } else {
-                if (p + 2 * k < n_row) { v.x = src[2 * k].x; v.y = src[2 * k].y; }
-                if (p + 2 * k + 1 < n_row) { v.z = src[2 * k + 1].x; v.w = src[2 * k + 1].y; }
-            }
-            s2v[i * halfG + k] = v;
+    // Every thread issues ALL its loads, then writes them to LDS: one round trip to memory per tile.  (Guarded
+    // loads compile to load -> wait -> LDS write, one after the other: four dependent round trips per thread,
+    // measured as 0.27 ms for the loads of the 10 000-channel launch.)  So the loads are unconditional: a group
+    // past the end of the row re-reads the last group -- whole groups are always allocated and written
+    // (k_stage12 stores Y2B outputs at a time), and entries >= n_row are never inside a FIR window.
+    const int p_last = (n_row - 1) & ~(G - 1);
+    auto group_src = [&](int i) -> const float2 * {
+        const int p = min(p0g + (i << gsh), p_last);
+        return p < a.hist ? hin + p : ynew + y2_group_index(a, p - a.hist);
+    };
+    for (int i0 = 0; i0 < ngrp; i0 += 512) {
+        const int ia = i0 + tid, ib = i0 + tid + 256;
+        const float2 *sa = group_src(ia), *sb = group_src(ib);
+        if (G == 4) {
+            const v4f a0 = *reinterpret_cast<const v4f *>(sa), a1 = *reinterpret_cast<const v4f *>(sa + 2);
+            const v4f b0 = *reinterpret_cast<const v4f *>(sb), b1 = *reinterpret_cast<const v4f *>(sb + 2);
+            if (ia < ngrp) { s2v[2 * ia] = a0; s2v[2 * ia + 1] = a1; }
+            if (ib < ngrp) { s2v[2 * ib] = b0; s2v[2 * ib + 1] = b1; }
+        } else {
+            const v4f a0 = *reinterpret_cast<const v4f *>(sa);
+            const v4f b0 = *reinterpret_cast<const v4f *>(sb);
+            if (ia < ngrp) s2v[ia] = a0;
+            if (ib < ngrp) s2v[ib] = b0;
         }
     }
     __syncthreads();
