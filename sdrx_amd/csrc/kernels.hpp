@@ -1,32 +1,39 @@
 // kernels.hpp -- gfx950 (MI355X, CDNA4) kernels of the sdrx channel bank.
 //
-// Three kernels per IQ block, launched back to back on the bank's stream:
+// Per IQ block, back to back on the bank's stream:
 //
-//   k_stage12   NCO mixer + decimator stages 1 and 2 fused (reference MSD::decimate mixer path
-//               src/msd.hpp:132-155 + S::addSample/calculateOutput msd.hpp:228-335 for the first
-//               two stages).  > 90 % of all work: stage 1 runs at the full input rate.
-//   k_tail      remaining one or two stages (msd.hpp:251-335 again), output [ch][out_stride].
-//   k_agc       IF AGC -> |.| -> LF AGC (src/agc.hpp:48-69, sdrx.cpp:178-180, agc.hpp:106-131).
+//   k_stage12      NCO mixer + decimator stages 1 and 2 fused (reference MSD::decimate mixer path
+//                  src/msd.hpp:132-155 + S::addSample/calculateOutput msd.hpp:228-335 for the first
+//                  two stages).  > 90 % of all arithmetic: stage 1 runs at the full input rate.
+//   k_tail_s/k_tail remaining one or two stages (msd.hpp:251-335 again), output [ch][out_stride];
+//                  k_tail_s has the stages' (m, taps) as template parameters, k_tail takes them at run time.
+//   k_agc<SQ, FM>  IF AGC -> |.| (or the FM phase step) -> LF AGC (src/agc.hpp:48-69, sdrx.cpp:178-194,
+//                  agc.hpp:106-131), gated by the squelch state (sdrx.cpp:458-503) when SQ; one extra
+//                  block rolls the input history to the front of the ring.
+// Optional, after those:
+//   k_squelch      window x 512-point FFT -> SNR -> open/close (sdrx.cpp:533-573)
+//   k_audio_fir    FIR / FIR2 (src/fir.hpp:79-183) on audio rows
+//   k_mix_partial / k_mix_reduce / k_mix_out   pan-mix of all channels, S16 (sdrx.cpp:469-497, 649-656)
 //
-// Design of k_stage12 (see DESIGN.md for the derivation):
-//   * one wavefront = ONE channel; its 64 lanes are 64 time segments spaced exactly N input
-//     samples apart (N = translator length).  Lane l therefore meets translator entry
-//     t[(phase + i) mod N] at the same loop step i as every other lane: the NCO value is
-//     WAVE-UNIFORM and comes through the scalar unit (s_load -> SGPR operand of the VALU
-//     multiply), costing no vector memory and no LDS traffic.  The table the caller built with
-//     the reference formula is used as is (no on-device sincos: the reference table carries
-//     float-rounded phases).
-//   * the W wavefronts of a workgroup are W different channels over the SAME 64 time segments,
-//     so they share one input tile: 64 rows x SB samples of the IQ stream staged once in LDS
-//     (coalesced global reads along rows) and read row-per-lane with a padded row stride
-//     (conflict-free ds_read_b128).  Input bytes from L2 per channel-sample = 8/W.
-//   * per lane the 17-/19-tap delay lines of stages 1 and 2 live in VGPRs (fully unrolled
-//     bodies of SB = M1*M2*Y2B samples, static indexing -> pure register renaming);
-//     filter taps are kernel arguments = SGPRs; folded symmetric FIR exactly like the reference.
+// Design of k_stage12 (see DESIGN.md 4.1 for the derivation and the measurements behind each choice):
+//   * the 64 lanes of a wavefront = CPW channels x 64/CPW time segments spaced a multiple of N input
+//     samples apart (N = translator length).  All lanes of one channel therefore meet the same
+//     translator entry at the same loop step: one LDS row per channel, read as a broadcast.  The
+//     table the caller built with the reference formula is used as is (no on-device sincos: the
+//     reference table carries float-rounded phases).
+//   * the W wavefronts of a workgroup are W*CPW channels over the SAME time segments, so they share
+//     one input tile.  Tiles (input rows + translator rows, SB samples each) go global -> LDS by
+//     LDS-DMA (global_load_lds_dwordx4), double-buffered, one barrier per body; rows are padded to a
+//     pitch that keeps ds_read_b128 conflict-free.
+//   * per lane the delay lines of stages 1 and 2 live in VGPRs (fully unrolled bodies of
+//     SB = M1*M2*Y2B samples, static indexing -> pure register renaming); arithmetic is packed fp32
+//     (one complex sample = one 64-bit register pair); filter taps are kernel arguments = SGPRs;
+//     folded symmetric FIR exactly like the reference.
 //   * no per-channel delay-line state is kept between blocks: the FIR cascade is non-recursive,
 //     so a lane re-creates its history by running WU warm-up bodies over the samples in front
 //     of its segment (the bank keeps the last few input samples of the previous block).
-//   * stage-2 outputs go to a per-channel scratch row in time order; k_tail picks them up.
+//   * stage-2 outputs go to a per-channel scratch row in BODY-MAJOR order (full-line writes); the
+//     tail kernels undo the permutation while they stage their tiles.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
