@@ -135,14 +135,14 @@ __device__ __forceinline__ v2f folded_fir_pk(const v2f (&w)[T], const float *__r
     v2f s[half];
 #pragma unroll
     for (int i = 0; i < half; i++) s[i] = w[i] + w[T - 1 - i];
-    v2f acc0 = s[0] * v2f{h[0], h[0]};
-    v2f acc1 = w[half] * v2f{h[half], h[half]};
+    // one accumulator, the reference's order (msd.hpp:309-332: pairs first, centre tap last).  The pair sums are
+    // independent of the chain, so the scheduler puts one between any two dependent FMAs (a packed op needs one
+    // wait state after the instruction that wrote its source); two interleaved accumulators cost an extra add per
+    // output (3.7 % of the kernel's instructions) for nothing.
+    v2f acc = s[0] * v2f{h[0], h[0]};
 #pragma unroll
-    for (int i = 1; i < half; i++) {
-        if (i & 1) acc1 = __builtin_elementwise_fma(s[i], v2f{h[i], h[i]}, acc1);
-        else       acc0 = __builtin_elementwise_fma(s[i], v2f{h[i], h[i]}, acc0);
-    }
-    return acc0 + acc1;
+    for (int i = 1; i < half; i++) acc = __builtin_elementwise_fma(s[i], v2f{h[i], h[i]}, acc);
+    return __builtin_elementwise_fma(w[half], v2f{h[half], h[half]}, acc);
 }
 
 // ------------------------------------------------------------------------------------------
