@@ -549,18 +549,21 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
     v2f *s3 = reinterpret_cast<v2f *>(smem) + 2 * npair;   // stage-A outputs, after the span
 
     const int n_row = a.hist + a.n_y2_new;                 // valid row entries
-    for (int i = tid; i < npair; i += blockDim.x) {
-        const int p = p0a + 2 * i;
-        v4f v;
-        // (a pair never straddles a body's group of Y2B outputs: p - hist is even and Y2B is even)
-        if (p + 1 < n_row) {
-            v = p < a.hist ? *reinterpret_cast<const v4f *>(hin + p)
-                           : *reinterpret_cast<const v4f *>(ynew + y2_storage_index(a, p - a.hist));
-        } else {                                           // last pair may reach one entry past the data
-            const float2 lo = p < n_row ? (p < a.hist ? hin[p] : ynew[y2_storage_index(a, p - a.hist)]) : make_float2(0.f, 0.f);
-            v = v4f{lo.x, lo.y, 0.f, 0.f};
-        }
-        s2v[i] = v;
+    // all loads of a thread first, then its LDS writes (guarded loads would serialise into load -> wait -> write
+    // per piece, see k_tail_s); a pair past the end of the row re-reads the last pair (never inside a FIR window),
+    // and the second entry of the last pair, when n_row is odd, lies inside the same allocated group of Y2B
+    const int p_lastpair = (n_row - 1) & ~1;
+    auto pair_src = [&](int i) -> const v4f * {
+        const int p = min(p0a + 2 * i, p_lastpair);
+        return reinterpret_cast<const v4f *>(p < a.hist ? hin + p : ynew + y2_storage_index(a, p - a.hist));
+    };
+    for (int i0 = 0; i0 < npair; i0 += 4 * 256) {
+        v4f v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = *pair_src(i0 + tid + 256 * u);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + tid + 256 * u < npair) s2v[i0 + tid + 256 * u] = v[u];
     }
     __syncthreads();
 
