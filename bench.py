@@ -191,12 +191,15 @@ def main():
         host = np.stack([synth.synth_iq(1234, b * L, L, 0.25, car, [0.3, 0.1], ch.N, ch.fs // 1000).view(np.float32).reshape(L, 2)
                          for b in range(n_ring)])
         ring = torch.from_numpy(host).cuda()
-    fan = sdist.BlockFanout(dist, blk, src=0)
-
     def run(offsets, steps, warmup):
         tabs = sb.translators_for(ch, offsets)
         bank = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, stream=tstream.cuda_stream, block_hint=args.block_hint,
                               pipelined=args.pipelined)
+        # N > 1: the broadcast lands directly in the bank's ingest buffer (its address is the same for every whole
+        # block), so process_device finds the block in place; should the address ever differ the call copies
+        ing_ptr, ing_cap = bank.ingest_buffer()
+        recv = torch.as_tensor(sb.DeviceView(ing_ptr, (L, 2)), device="cuda") if ing_cap >= L else blk
+        fan = sdist.BlockFanout(dist, recv, src=0)
         d_iq = torch.empty(len(offsets), 512, 2, dtype=torch.float32, device="cuda")
         d_au = torch.empty(len(offsets), 512, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
