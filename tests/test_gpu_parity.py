@@ -499,3 +499,47 @@ def test_profile_counters():
     ms_t, n_t = bank.profile_read(sb.K_TOTAL)
     assert n_t == 3 and ms_t >= ms
     bank.close()
+
+
+def test_two_blocks_per_call_with_a_larger_max_in_len(oracle):
+    """max_in_len = 2 blocks: one call produces 1024 outputs per channel (longer scratch rows, more time-waves)."""
+    ch = chains.chain("10")
+    offs = chains.offsets_cycled(40, ch.N)
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    x = synth.synth_iq(77, 0, 4 * L, 0.25, [tabs[3]], [0.2], ch.N, 9000)
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), max_in_len=2 * L)
+    one = sb.ChannelBank(tabs, ch.stage_tuples())
+    got, ref = [], []
+    for k in range(2):
+        iq, au = bank.process(x[2 * k * L:(2 * k + 2) * L])
+        assert iq.shape == (40, 1024)
+        got.append((iq, au))
+        parts = [one.process(x[(2 * k + j) * L:(2 * k + j + 1) * L]) for j in range(2)]
+        ref.append((np.concatenate([p[0] for p in parts], axis=1), np.concatenate([p[1] for p in parts], axis=1)))
+    for (iq, au), (riq, rau) in zip(got, ref):
+        assert np.array_equal(iq.view(np.uint32), riq.view(np.uint32))      # the split of the stream never changes a result
+        assert np.array_equal(au.view(np.uint32), rau.view(np.uint32))
+    y = oracle.msd(tabs[3], ch.stage_tuples()).decimate(x)
+    assert rel_err(np.concatenate([g[0][3] for g in got]), y) <= RTOL
+    bank.close()
+    one.close()
+
+
+def test_many_channels_beyond_the_benchmark_size(oracle):
+    """25 000 channel instances in one bank (2.7 GB of stage-2 scratch): sampled against the oracle, and every
+    instance of the same offset bit-identical."""
+    ch = chains.chain("10")
+    n = 25000
+    offs = chains.offsets_cycled(n, ch.N)
+    tabs_u = {o: t for o, t in zip(offs[:ch.N], sb.translators_for(ch, offs[:ch.N]))}
+    tabs = [tabs_u[o] for o in offs]
+    x = synth.synth_iq(5, 0, ch.block_len, 0.25, [tabs[700]], [0.2], ch.N, 9000)
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    iq, au = bank.process(x)
+    bank.close()
+    for c in (0, 700, 12345, n - 1):
+        y = oracle.msd(tabs[c], ch.stage_tuples()).decimate(x)
+        assert rel_err(iq[c], y) <= RTOL
+    assert np.array_equal(iq[700].view(np.uint32), iq[700 + ch.N].view(np.uint32))
+    assert np.array_equal(au[123].view(np.uint32), au[123 + 20 * ch.N].view(np.uint32))
