@@ -264,9 +264,12 @@ static int dev_alloc(sdrxgpu_bank *b, void **p, size_t bytes)
     return SDRXGPU_OK;
 }
 
+static thread_local sdrxgpu_bank *g_creating = nullptr;   // bank under construction (freed if an exception ends bank_create)
+
 static void free_bank(sdrxgpu_bank *b)
 {
     if (!b) return;
+    if (g_creating == b) g_creating = nullptr;
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (ProfSpan &s : b->prof_pending) {
         (void)hipEventDestroy(s.a);
@@ -335,7 +338,25 @@ static int init_state(sdrxgpu_bank *b)
     return SDRXGPU_OK;
 }
 
+static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out);
+
 extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
+{
+    // no C++ exception may cross the C ABI (host-side staging vectors of a very large bank can fail to allocate)
+    try {
+        const int rc = bank_create_impl(cfg, out);
+        g_creating = nullptr;
+        return rc;
+    } catch (const std::bad_alloc &) {
+        free_bank(g_creating);
+        return fail(SDRXGPU_ERR_NO_MEM, "bank_create: host allocation failed");
+    } catch (const std::exception &e) {
+        free_bank(g_creating);
+        return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: %s", e.what());
+    }
+}
+
+static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
 {
     if (!cfg || !out) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: null argument");
     *out = nullptr;
@@ -382,6 +403,7 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
 
     sdrxgpu_bank *b = new (std::nothrow) sdrxgpu_bank();
     if (!b) return fail(SDRXGPU_ERR_NO_MEM, "bank_create: host allocation failed");
+    g_creating = b;
     b->device = dev;
     b->n_ch = cfg->n_channels;
     b->n_stages = cfg->n_stages;
