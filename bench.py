@@ -86,6 +86,9 @@ def cpu_baseline(chain, seconds=12.0):
     }
 
 
+SETTLE_STEPS = 120
+
+
 def time_bank(bank, fan, ring, rank, world, dist, L, d_iq, d_au, steps, warmup, n_ring):
     """W untimed warm-up steps, then exactly `steps` timed steps bracketed by synchronize + barrier."""
     def step(i):
@@ -94,11 +97,17 @@ def time_bank(bank, fan, ring, rank, world, dist, L, d_iq, d_au, steps, warmup, 
         n = bank.process_device(cur.data_ptr(), L, d_iq.data_ptr(), d_au.data_ptr(), 512)
         assert n == 512 or (i == 0 and n == 0)      # a pipelined bank returns block k-1 at call k
 
-    for i in range(warmup):
+    # Clock settling, untimed and in front of the W warm-up steps: from idle the chip needs ~50 ms of this load before
+    # its clock is steady (measured per step: 1.24, 1.35, 1.61, 1.52, ... 1.22 at step 12, 1.15 from step ~40 on).
+    # A fixed number of steps, the same on every rank (each step is a collective when N > 1).
+    for i in range(SETTLE_STEPS):
         step(i)
+    for i in range(warmup):
+        step(SETTLE_STEPS + i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    warmup += SETTLE_STEPS           # (ring index of the timed steps below)
     bank.profile_reset()
     bank.profile_enable(2)      # HIP events around the dominant kernel only (roofline.achieved comes from the timed region)
     torch.cuda.synchronize()
@@ -147,8 +156,8 @@ def measured_traffic(n_ch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=10000, help="channel instances per GPU")
     ap.add_argument("--rate", default="10")
     ap.add_argument("--block-hint", type=int, default=0)
@@ -309,6 +318,7 @@ def main():
                 "outputs_per_channel_per_block": 512,
                 "parallelism": f"channel-sharded x{world}" + (", RCCL broadcast of the IQ block per step" if world > 1 else ""),
                 "realtime_factor": value * 1e6 / (n_ch * world * ch.fs),
+                "settle_steps": SETTLE_STEPS,    # untimed, before the W warm-up steps (clock settling, see time_bank)
                 "call_semantics": "drop-in: call k returns block k" if not args.pipelined else
                                   "pipelined: call k returns block k-1 (bit-identical outputs, one block of latency)",
             },
