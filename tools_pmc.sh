@@ -12,7 +12,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "WRITE_SIZE" \
            "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs "$@" > $OUT/pass$i.log 2>&1
+  timeout -k 10 240 rocprofv3 --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra-configs "$@" > $OUT/pass$i.log 2>&1
   echo "pass $i ($SET): exit $?"
 done
 python3 - <<PY
