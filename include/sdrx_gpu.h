@@ -45,16 +45,19 @@ extern "C" {
 #define SDRXGPU_ERR_UNSUPPORTED   -5   /* stage chain / translator length the kernels do not cover */
 #define SDRXGPU_ERR_OUT_TOO_SMALL -6   /* out_stride smaller than the outputs this call produces  */
 
-/* flags */
+/* sdrxgpu_bank_cfg.modulation[] values (Channel::mod, sdrx.cpp:151/230) */
 #define SDRXGPU_MOD_AM 0
 #define SDRXGPU_MOD_FM 1
+
+/* sdrxgpu_bank_cfg.flags */
 #define SDRXGPU_FLAG_LF_AGC_ACTIVE 0x1u  /* --lf-agc: LfAGC::activate(), sdrx.cpp:1710 */
 #define SDRXGPU_FLAG_FTFIR         0x4u  /* --ftfir (EXPERIMENTAL in the reference, sdrx.cpp:1199): MSD's use_ftfir, msd.hpp:104-131 */
 #define SDRXGPU_FLAG_PIPELINED     0x2u  /* throughput mode for sdrxgpu_bank_process_device only: call k launches the
                                             mixer + stages 1-2 of block k concurrently with the remaining stages and
                                             the AGC/demod of block k-1, and returns the outputs of block k-1 (one block
                                             = 32 ms of latency, like one more chunk in sdrx's ring of 8, sdrx.cpp:1742);
-                                            sdrxgpu_bank_flush returns the last block.  Same outputs, bit for bit. */
+                                            sdrxgpu_bank_flush returns the last block.  Same outputs, bit for bit.
+                                            Measured: no faster than the default serial order. */
 
 typedef struct sdrxgpu_bank sdrxgpu_bank;
 
