@@ -87,6 +87,17 @@ typedef struct {
     float init_gain, init_power;
 } sdrxgpu_agc_params;
 
+/* Geometry / kernel-path overrides for tests and tuning runs.  NULL in sdrxgpu_bank_cfg.tuning (the default) =
+ * everything automatic.  Every choice computes the same outputs (tests/test_gpu_parity.py); a choice whose
+ * tiles do not fit the CU's LDS, or that is not compiled for the chain, makes sdrxgpu_bank_create fail. */
+typedef struct {
+    uint32_t k12_waves;      /* waves per workgroup of the stage-1/2 kernel: 4, 8 or 16; 0 = auto            */
+    uint32_t k12_cpw;        /* channels per wave of that kernel: 1, 2 or 4; 0 = auto                         */
+    uint32_t tail_tile;      /* final outputs per workgroup of the separate tail kernel, 8..128; 0 = auto     */
+    uint32_t tail_generic;   /* 1 = run-time-tap tail kernel even where a compile-time one exists             */
+    uint32_t fused_tail;     /* 0 = auto; 1 = never run stage 3 inside the stage-1/2 kernel; 2 = require it   */
+} sdrxgpu_tuning;
+
 typedef struct {
     uint32_t               struct_size;  /* = sizeof(sdrxgpu_bank_cfg) */
     uint32_t               flags;        /* SDRXGPU_FLAG_* */
@@ -136,6 +147,7 @@ typedef struct {
      * reference): NULL = every channel AM.  SDRXGPU_MOD_FM channels get Demod::demod's FM branch (sdrx.cpp:181-194)
      * in place of std::abs: audio = atan2 of the phase step between consecutive amplitude-normalised AGC outputs. */
     const uint8_t         *modulation;
+    const sdrxgpu_tuning  *tuning;       /* NULL = automatic (what a host application passes) */
 } sdrxgpu_bank_cfg;
 
 typedef struct {

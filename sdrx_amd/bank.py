@@ -42,6 +42,14 @@ class AgcParams(C.Structure):
     _fields_ = [(k, C.c_float) for k in ("attack", "decay", "reference", "max_gain", "alpha", "init_gain", "init_power")]
 
 
+class Tuning(C.Structure):
+    """sdrxgpu_tuning: geometry / kernel-path overrides for tests and tuning runs (0 = automatic)."""
+    _fields_ = [(k, C.c_uint32) for k in ("k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail")]
+
+
+FUSED_AUTO, FUSED_OFF, FUSED_REQUIRE = 0, 1, 2
+
+
 class _Cfg(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32),
                 ("n_stages", C.c_uint32), ("stages", C.POINTER(_Stage)),
@@ -54,7 +62,7 @@ class _Cfg(C.Structure):
                 ("ramp_up", C.POINTER(C.c_float)), ("ramp_down", C.POINTER(C.c_float)),
                 ("pan_pos", C.POINTER(C.c_int8)), ("mix_fir_taps", C.POINTER(C.c_float)),
                 ("n_mix_fir_taps", C.c_uint32), ("mix_fir_gain_db", C.c_float),
-                ("modulation", C.POINTER(C.c_uint8))]
+                ("modulation", C.POINTER(C.c_uint8)), ("tuning", C.POINTER(Tuning))]
 
 
 class BankInfo(C.Structure):
@@ -206,7 +214,7 @@ class ChannelBank:
     def __init__(self, translators, stages, lf_agc=False, agc=None, agc_lf=None, device=-1, stream=None,
                  max_in_len=0, block_hint=0, pipelined=False, ftfir=False,
                  audio_fir=None, audio_fir_gain_db=0.0, squelch=None, pan_pos=None, mix_fir=None, mix_fir_gain_db=0.0,
-                 modulation=None):
+                 modulation=None, tuning=None):
         L = load_library()
         self._L = L
         n_ch = len(translators)
@@ -261,6 +269,10 @@ class ChannelBank:
                 cfg.mix_fir_taps = self._mixfir.ctypes.data_as(C.POINTER(C.c_float))
                 cfg.n_mix_fir_taps = len(self._mixfir)
                 cfg.mix_fir_gain_db = mix_fir_gain_db
+        if tuning is not None:
+            # dict of sdrxgpu_tuning fields, e.g. {"k12_waves": 8, "k12_cpw": 4} (tests / tuning runs only)
+            self._tuning = Tuning(**tuning)
+            cfg.tuning = C.pointer(self._tuning)
         h = C.c_void_p()
         _check(L.sdrxgpu_bank_create(C.byref(cfg), C.byref(h)), "sdrxgpu_bank_create")
         self._h = h

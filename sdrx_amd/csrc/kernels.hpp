@@ -276,11 +276,7 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
             dma_row<SB>(xsrc + (size_t)b * SB + (size_t)r * a.spacing, buf + r * G::row_bytes, lane);
 #pragma unroll
         for (int c = 0; c < CPW; c++) {
-#ifdef SDRX_EXP_SAMETABLE
-            const int tc = 0;   // timing experiment only: every wave reads channel 0's table
-#else
             const int tc = min(ch0 + c, a.n_ch - 1);
-#endif
             dma_row<SB>(tables + (size_t)tc * a.tbl_stride + tphb, buf + (SPW + wave * CPW + c) * G::row_bytes, lane);
         }
     };
@@ -303,9 +299,6 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
     v2f y2v[Y2B];
     auto store_y2 = [&](int body) {          // body = 0 .. nb-1 (real bodies only)
         if (!ch_ok) return;
-#ifdef SDRX_EXP_NOSTORE
-        if (a.n_ch > 0) return;   // timing experiment only: arithmetic stays live, nothing is written
-#endif
         float2 *dst = ydst + (size_t)body * SPW * Y2B;
         if (Y2B % 2 == 0) {
 #pragma unroll

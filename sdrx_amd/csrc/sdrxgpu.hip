@@ -209,7 +209,7 @@ struct sdrxgpu_bank {
     float2 *d_hist[2] = {nullptr, nullptr};   // stage-2 history, ping-pong between calls
     int hist_cur = 0;
     int tile_b = 64;                          // final outputs per k_tail workgroup (64: 8 workgroups per CU)
-    bool tail_generic = false;                // SDRXGPU_TAIL_GENERIC=1: run-time-tap k_tail even for the compiled-in chains
+    bool tail_generic = false;                // tuning.tail_generic: run-time-tap k_tail even for the compiled-in chains
     size_t tail_lds = 0;
     float *d_audio_keep = nullptr;
     float4 *d_state = nullptr;
@@ -447,8 +447,15 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     b->keep_stride = (((int)(b->max_chunk / b->m_total) + 1 + 3) / 4) * 4;   // rows stay 16-byte aligned
 
     // LDS of one k_tail tile: the stage-2 span of tile_b outputs (+ FIR history) and its stage-A outputs
-    if (const char *e = getenv("SDRXGPU_TAIL_TILE")) b->tile_b = std::max(8, std::min(128, atoi(e)));
-    if (const char *e = getenv("SDRXGPU_TAIL_GENERIC")) b->tail_generic = atoi(e) != 0;
+    const sdrxgpu_tuning tune = cfg->tuning ? *cfg->tuning : sdrxgpu_tuning{};
+    if (tune.tail_tile) {
+        if (tune.tail_tile < 8 || tune.tail_tile > 128) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.tail_tile %u (8..128)", tune.tail_tile);
+        }
+        b->tile_b = (int)tune.tail_tile;
+    }
+    b->tail_generic = tune.tail_generic != 0;
     {
         const int tB = (int)b->ntaps[cfg->n_stages - 1], mB = (int)b->m[cfg->n_stages - 1];
         size_t np, nr = 0;
@@ -505,11 +512,13 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 }
             }
         }
-        if (const char *e = getenv("SDRXGPU_K12_W")) b->W = atoi(e);
-        if (const char *e = getenv("SDRXGPU_K12_CPW")) b->CPW = atoi(e);
-        if (!k12_geometry_compiled(k12->level, b->W, b->CPW)) {
+        if (tune.k12_waves) b->W = (int)tune.k12_waves;
+        if (tune.k12_cpw) b->CPW = (int)tune.k12_cpw;
+        if (!k12_geometry_compiled(k12->level, b->W, b->CPW) ||
+            2 * (size_t)(kWave / b->CPW + b->W * b->CPW) * (b->SB * 8 + 16) > 160 * 1024) {
             free_bank(b);
-            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: stage-1/2 geometry W=%d CPW=%d is not compiled for this chain", b->W, b->CPW);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: stage-1/2 geometry W=%d CPW=%d is not compiled for this chain or does not fit the LDS",
+                        b->W, b->CPW);
         }
         if (cfg->block_hint == 0xFFFFFFFFu) {
             b->nb = b->bps;                   // whole segment per lane (P == 1)
@@ -867,7 +876,11 @@ extern "C" int sdrxgpu_bank_profile_reset(sdrxgpu_bank *b)
 // ------------------------------------------------------------------------------------------
 // one chunk (<= max_chunk samples, already at d_x + HIST) through the three kernels
 // ------------------------------------------------------------------------------------------
-static long long floordiv(long long a, long long b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+// outputs per channel that `len` samples arriving at stream position n0 yield (MSD::decimate's *out_len_ptr, msd.hpp:158)
+static size_t outputs_of(const sdrxgpu_bank *b, uint64_t n0, size_t len)
+{
+    return (size_t)((n0 + len) / b->m_total - n0 / b->m_total);
+}
 
 // Stage-1/2 of one chunk (<= max_chunk samples, already in the input ring) on stream `st`; fills `job` with
 // everything the tail launch needs except the output pointers and the history ping-pong side.
@@ -1008,17 +1021,13 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     *produced = 0;
     if (!job->valid) return SDRXGPU_OK;
     TailArgs &t = job->t;
-    job->valid = false;
-    // a call refused here must still leave the input ring consistent: do the history roll k_agc would have done
-    auto refuse = [&](int code) {
-        if (job->roll_cnt > 0) hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(1024), 0, b->stream, b->d_x, job->roll_src, job->roll_cnt);
-        job->roll_cnt = 0;
-        return code;
-    };
+    // (process_impl / bank_flush have validated out_stride and the squelch's 512-output rule before anything was
+    // launched; these two are internal consistency checks and leave the job untouched)
     if (out_off + (size_t)t.n_b > out_stride && (d_iq_out || d_audio_out))
-        return refuse(fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride));
+        return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "internal: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride);
     if (b->squelch && t.n_b != 512)
-        return refuse(fail(SDRXGPU_ERR_UNSUPPORTED, "process: a bank with squelch takes whole 512-output chunks (this call produces %d)", t.n_b));
+        return fail(SDRXGPU_ERR_UNSUPPORTED, "internal: squelch chunk of %d outputs", t.n_b);
+    job->valid = false;
     t.hist_in = b->d_hist[b->hist_cur];
     t.hist_out = b->d_hist[b->hist_cur ^ 1];
     t.iq_out = d_iq_out ? d_iq_out + out_off : nullptr;
@@ -1193,6 +1202,24 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
         return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a pipelined bank takes device pointers and at most max_in_len samples per call");
     if (b->mix && in_len > b->max_chunk)
         return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a bank with mix-down takes at most max_in_len = %u samples per call", b->max_chunk);
+    // Everything that can refuse the call is checked HERE, before any launch or state change: a refused call
+    // leaves the bank exactly as it was (MSD::decimate cannot fail, msd.hpp:75; the next call must still be right).
+    {
+        uint64_t pos = b->n_in;
+        size_t left = in_len, total_out = 0;
+        while (left) {
+            const size_t n = std::min(left, (size_t)b->max_chunk);
+            const size_t k = outputs_of(b, pos, n);
+            if (b->squelch && (pos + n) / b->MM > pos / b->MM && k != 512)
+                return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a bank with squelch takes whole 512-output chunks (this call produces %zu)", k);
+            total_out += k;
+            pos += n;
+            left -= n;
+        }
+        const size_t returned = b->pipelined ? (b->pending.valid ? (size_t)b->pending.t.n_b : 0) : total_out;
+        if ((iq_out || audio_out) && returned > out_stride)
+            return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", returned, out_stride);
+    }
     HIPCHK(hipSetDevice(b->device));
     if (b->mix && !b->pipelined) b->mix_frames = 0;
     ProfScope total(b, SDRXGPU_K_TOTAL);
@@ -1214,9 +1241,6 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
             rc = run_chunk(b, n, nullptr, nullptr, b->keep_stride, 0, &produced);
             if (rc) return rc;
             if (produced) {
-                if ((iq_out || audio_out) && produced_total + produced > out_stride)
-                    return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu",
-                                produced_total + produced, out_stride);
                 if (iq_out)
                     HIPCHK(hipMemcpy2DAsync((float2 *)iq_out + produced_total, out_stride * sizeof(float2), b->d_keep,
                                             (size_t)b->keep_stride * sizeof(float2), produced * sizeof(float2), b->n_ch,
@@ -1256,6 +1280,8 @@ extern "C" int sdrxgpu_bank_process_device(sdrxgpu_bank *b, const void *d_iq_in,
 extern "C" int sdrxgpu_bank_flush(sdrxgpu_bank *b, void *d_iq_out, void *d_audio_out, size_t out_stride, size_t *out_len)
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "flush: null bank");
+    if (b->pending.valid && (d_iq_out || d_audio_out) && (size_t)b->pending.t.n_b > out_stride)
+        return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "flush: %d outputs per channel but out_stride is %zu", b->pending.t.n_b, out_stride);
     HIPCHK(hipSetDevice(b->device));
     size_t produced = 0;
     int rc = launch_tail(b, &b->pending, (float2 *)d_iq_out, (float *)d_audio_out, out_stride, 0, &produced);

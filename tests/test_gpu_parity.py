@@ -115,16 +115,14 @@ def test_every_time_tiling_gives_the_same_answer(hint):
 
 
 @pytest.mark.parametrize("w,cpw", [(16, 4), (16, 2), (16, 1), (8, 4), (8, 1), (4, 4), (4, 2), (4, 1)])
-def test_every_workgroup_geometry_gives_the_same_answer(w, cpw, monkeypatch):
+def test_every_workgroup_geometry_gives_the_same_answer(w, cpw):
     """Waves per workgroup / channels per wave of the stage-1/2 kernel must not show in the result."""
     ch = chains.chain("10")
     offs = list(range(-40, 37))            # 77 channels: not a multiple of any W*CPW
     tabs = sb.translators_for(ch, offs)
     blocks = [synth.synth_iq(8, b * ch.block_len, ch.block_len, 0.25) for b in range(2)]
     ref_bank = sb.ChannelBank(tabs, ch.stage_tuples())
-    monkeypatch.setenv("SDRXGPU_K12_W", str(w))
-    monkeypatch.setenv("SDRXGPU_K12_CPW", str(cpw))
-    bank = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=4)
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=4, tuning={"k12_waves": w, "k12_cpw": cpw})
     for x in blocks:
         a, b = ref_bank.process(x)
         c, d = bank.process(x)
@@ -465,6 +463,50 @@ def test_squelch_and_gated_audio_vs_oracle(oracle):
         bank.process(blocks[0][:1000])
     assert e.value.code == -5
     bank.close()
+
+
+def test_refused_call_leaves_the_bank_untouched():
+    """A call the library refuses (out_stride too small; squelch bank fed less than a 512-output chunk) must change
+    nothing: the calls after it give the same bits as an uninterrupted run.  MSD::decimate cannot fail (msd.hpp:75),
+    so a refusal is this library's own and may not cost the stream its state."""
+    import torch
+    ch = chains.chain("10")
+    offs = [0, 5, -7, 599, -600]
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    blocks = [synth.synth_iq(41, b * L, L, 0.25, [tabs[1]], [0.3], ch.N, 10000) for b in range(3)]
+    pb, ru, rd = chains.squelch_tables()
+    for kw in ({}, {"squelch": (np.array([0.0, 6.0, 6.0, 0.0, 3.0], np.float32), pb, ru, rd)}):
+        ref = sb.ChannelBank(tabs, ch.stage_tuples(), **kw)
+        want = [ref.process(x) for x in blocks]
+        ref.close()
+        bank = sb.ChannelBank(tabs, ch.stage_tuples(), **kw)
+        got = [bank.process(blocks[0])]
+        # host-pointer entry: room for 100 outputs per channel, the call yields 512
+        small_iq = np.zeros((len(offs), 100), np.complex64)
+        small_au = np.zeros((len(offs), 100), np.float32)
+        with pytest.raises(sb.SdrxGpuError) as e:
+            bank.process(blocks[1], iq_out=small_iq, audio_out=small_au)
+        assert e.value.code == -6
+        # device-pointer entry, same refusal
+        d_in = torch.from_numpy(blocks[1].view(np.float32).reshape(L, 2).copy()).cuda()
+        d_iq = torch.zeros(len(offs), 100, 2, device="cuda")
+        d_au = torch.zeros(len(offs), 100, device="cuda")
+        with pytest.raises(sb.SdrxGpuError) as e:
+            bank.process_device(d_in.data_ptr(), L, d_iq.data_ptr(), d_au.data_ptr(), 100)
+        assert e.value.code == -6
+        if kw:
+            with pytest.raises(sb.SdrxGpuError) as e:       # squelch: whole 512-output chunks only
+                bank.process(blocks[1][: L // 2])
+            assert e.value.code == -5
+        info = bank.info()
+        assert info.samples_in == L and info.samples_out == 512
+        got.append(bank.process(blocks[1]))
+        got.append(bank.process(blocks[2]))
+        bank.close()
+        for (a, b), (c, d) in zip(want, got):
+            assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+            assert np.array_equal(b.view(np.uint32), d.view(np.uint32))
 
 
 def test_error_behaviour():

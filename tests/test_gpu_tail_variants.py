@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 WHOLE = 0xFFFFFFFF      # block_hint: a whole segment per lane (the layout of a large bank)
 
 
-def _run(monkeypatch, generic, rate, offs, blocks, hint):
-    monkeypatch.setenv("SDRXGPU_TAIL_GENERIC", "1" if generic else "0")
+def _run(generic, rate, offs, blocks, hint, fused=sb.FUSED_OFF):
     ch = chains.chain(rate)
-    bank = sb.ChannelBank(sb.translators_for(ch, offs), ch.stage_tuples(), block_hint=hint)
+    bank = sb.ChannelBank(sb.translators_for(ch, offs), ch.stage_tuples(), block_hint=hint,
+                          tuning={"tail_generic": int(generic), "fused_tail": fused})
     iq = []
     for x in blocks:
         iq.append(bank.process(x, want_audio=False)[0])
@@ -23,7 +23,7 @@ def _run(monkeypatch, generic, rate, offs, blocks, hint):
 
 
 @pytest.mark.parametrize("rate", ["10", "2.4", "0.96", "1.2", "1.44", "1.6", "1.92", "6", "2.56"])
-def test_specialised_and_generic_tail_kernels_match_the_oracle(oracle, monkeypatch, rate):
+def test_specialised_and_generic_tail_kernels_match_the_oracle(oracle, rate):
     ch = chains.chain(rate)
     offs = [0, 7, -11, 3, 1]
     L = ch.block_len
@@ -34,7 +34,7 @@ def test_specialised_and_generic_tail_kernels_match_the_oracle(oracle, monkeypat
     outs = {}
     for generic in (False, True):
         for hint in (0, WHOLE):                                # auto layout (P > 1 for a small bank) and P == 1
-            iq = _run(monkeypatch, generic, rate, offs, blocks, hint)
+            iq = _run(generic, rate, offs, blocks, hint)
             assert iq.shape == ref.shape
             assert rel_err_rows(iq, ref) <= RTOL, (rate, generic, hint)
             outs[(generic, hint)] = iq
@@ -45,7 +45,7 @@ def test_specialised_and_generic_tail_kernels_match_the_oracle(oracle, monkeypat
     assert rel_err_rows(outs[(False, 0)], outs[(True, 0)]) <= 2e-6
 
 
-def test_specialised_tail_many_channels_and_tiny_calls(oracle, monkeypatch):
+def test_specialised_tail_many_channels_and_tiny_calls(oracle):
     """300 channels (not a multiple of 8 or 16), calls from 0 to several blocks' worth of samples."""
     ch = chains.chain("10")
     offs = chains.offsets_cycled(300, ch.N)
@@ -57,8 +57,8 @@ def test_specialised_tail_many_channels_and_tiny_calls(oracle, monkeypatch):
     for n in lens:
         blocks.append(stream[p:p + n])
         p += n
-    a0 = _run(monkeypatch, False, "10", offs, blocks, WHOLE)
-    a1 = _run(monkeypatch, True, "10", offs, blocks, WHOLE)
+    a0 = _run(False, "10", offs, blocks, WHOLE)
+    a1 = _run(True, "10", offs, blocks, WHOLE)
     assert rel_err_rows(a0, a1) <= 2e-6
     for c in (0, 150, 299):
         y = oracle.msd(sb.translators_for(ch, [offs[c]])[0], ch.stage_tuples()).decimate(stream)
