@@ -158,6 +158,8 @@ typedef struct {
     uint64_t samples_in;       /* IQ samples consumed since create/reset */
     uint64_t samples_out;      /* outputs produced per channel since create/reset */
     uint64_t device_bytes;     /* HBM held by the bank */
+    uint32_t fused_tail;       /* 1: stage 3 runs inside the stage-1/2 kernel (large banks of the 4-stage chains) */
+    uint32_t reserved;
 } sdrxgpu_bank_info;
 
 /* Fill the AGC / LfAGC parameter blocks as sdrx configures them per channel

@@ -145,13 +145,51 @@ __device__ __forceinline__ v2f folded_fir_pk(const v2f (&w)[T], const float *__r
     return __builtin_elementwise_fma(w[half], v2f{h[half], h[half]}, acc);
 }
 
+// ---- folded FIR over a window in LDS (or in registers), fully unrolled, taps as SGPR operands -----------------
+// acc += x * h[K] on both halves, the tap read from one half of an SGPR pair (op_sel picks the half): two taps per
+// pair instead of the (h, h) pair per tap the compiler would build -- 45 taps of the 10 MS/s tail would otherwise
+// need 90 SGPRs and spill into v_readlane/v_writelane traffic.  The s_nop is the wait state a packed op needs
+// when its source was written by the instruction right before it (hipcc cannot see into the asm).
+template <int K>
+__device__ __forceinline__ void fma_tap(v2f &acc, const v2f x, const v2f hpair)
+{
+    if constexpr ((K & 1) == 0)
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "s"(hpair));
+    else
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "s"(hpair));
+}
+
+template <int T, int NH, int I = 0>
+__device__ __forceinline__ void folded_fir_steps(v2f &acc, const v2f *__restrict__ w, const float (&h)[NH])
+{
+    static_assert(NH % 2 == 0 && NH >= (T + 1) / 2, "tap array: an even number of entries covering h[0 .. (T-1)/2]");
+    constexpr int half = (T - 1) >> 1;
+    if constexpr (I <= half) {
+        const v2f hp = {h[I & ~1], h[(I & ~1) + 1]};
+        if constexpr (I < half)
+            fma_tap<I>(acc, w[I] + w[T - 1 - I], hp);
+        else
+            fma_tap<I>(acc, w[half], hp);
+        folded_fir_steps<T, NH, I + 1>(acc, w, h);
+    }
+}
+
+template <int T, int NH>
+__device__ __forceinline__ v2f folded_fir_unrolled(const v2f *__restrict__ w, const float (&h)[NH])
+{
+    v2f acc = {0.f, 0.f};
+    folded_fir_steps<T, NH>(acc, w, h);
+    return acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_stage12
 // ------------------------------------------------------------------------------------------
-template <int T1, int T2>
+template <int T1, int T2, int TA = 1>
 struct Stage12Taps {
     float h1[(T1 + 1) / 2];
     float h2[(T2 + 1) / 2];
+    float h3[(((TA + 1) / 2) + 1) & ~1];   // fused stage 3 only (an even number of entries: read as SGPR pairs)
 };
 
 // Pointer parameters of k_stage12 (separate __restrict__ kernel parameters):
@@ -174,6 +212,12 @@ struct Stage12Args {
     int n_wt;               // time-waves = G*P
     int n_chgroups;
     int n_cgx;              // n_chgroups rounded up to a multiple of 8 (XCD-aware block map)
+    // fused stage 3 (k_stage12<.., MA, TA> with MA > 0; P == 1): stage-3 output rr of this call (0-based) has the call's
+    // stage-2 outputs MA*rr + c0 - (TA-1) .. MA*rr + c0 as its window
+    int y3_stride;
+    int c0;
+    int n_y3;
+    float rcp_npc;          // 1 / (16-byte pieces of one workgroup range of one channel)
 };
 
 // LDS tile geometry.  A wave's 64 lanes are CPW channels x SPW = 64/CPW time segments (lane =
@@ -218,10 +262,17 @@ __device__ __forceinline__ void dma_row(const float2 *src_row /* wave-uniform */
 
 // First stages with a large decimation factor (6 MS/s: m=15/53 taps, 2.56 MS/s: m=20/51 taps) keep more
 // than 128 registers live; they run at a lower occupancy and without the double-buffered LDS reads.
-template <int M1, int T1, int M2, int T2, int Y2B, int W, int CPW>
+//
+// MA > 0: stage 3 (decimation MA, TA taps) of the workgroup's OWN range runs as an epilogue.  A workgroup with
+// P == 1 covers SPW whole segments = one contiguous range of RLEN stage-2 outputs for each of its W*CPW channels;
+// every stage-3 output whose window lies inside that range ("interior": all but the ~(TA-1)/MA outputs at each range
+// boundary) is computed here, from the range read back into the LDS the tiles no longer need (the range was written
+// by this workgroup's own waves, so it comes back under workgroup-scope ordering: s_waitcnt vmcnt(0) + barrier), and
+// goes to y3_out[ch][rr].  k_tail4 computes the boundary outputs from the stage-2 scratch and runs the last stage.
+template <int M1, int T1, int M2, int T2, int Y2B, int W, int CPW, int MA = 0, int TA = 1>
 __global__ __launch_bounds__(kWave * W, (M1 > 6 ? 1 : 4))
 void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
-               const Stage12Args a, const Stage12Taps<T1, T2> taps)
+               float2 *__restrict__ y3_out, const Stage12Args a, const Stage12Taps<T1, T2, TA> taps)
 {
     constexpr int SB = M1 * M2 * Y2B;                      // input samples per body
     constexpr int NY1 = M2 * Y2B;                          // stage-1 outputs per body
@@ -421,6 +472,63 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
         else run_body(std::false_type{});
     }
     store_y2(a.nb - 1);   // the last body's outputs
+
+    if constexpr (MA > 0) {
+        static_assert(Y2B == 4, "fused stage 3: groups of 4 stage-2 outputs (two 16-byte pieces)");
+        constexpr int LDS_BYTES = 2 * G::buf_bytes;
+        const int seg_y2 = a.nb * Y2B;                       // stage-2 outputs per segment (P == 1: nb = bodies per segment)
+        const int rlen = SPW * seg_y2;                       // ... per workgroup range
+        const int base = g * rlen;                           // first stage-2 output (index within the call) of this range
+        const int end = min(base + rlen, a.n_y2_new);
+        // interior outputs rr_lo .. rr_hi: window [MA*rr + c0 - (TA-1), MA*rr + c0] inside [base, end)
+        const int rr_lo = (base + (TA - 1) - a.c0 + MA - 1) / MA;
+        const int rr_hi = (end - 1 - a.c0 >= 0) ? min((end - 1 - a.c0) / MA, a.n_y3 - 1) : -1;
+        const int n_int = rr_hi - rr_lo + 1;
+        const int npc = rlen / 2;                            // 16-byte pieces per channel
+        const int cpp = min(W * CPW, LDS_BYTES / (rlen * 8));    // channels per pass (host: >= 1)
+        // every store of this workgroup's range has left its wave, and every wave is done with the tiles
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        v4f *__restrict__ lds4 = reinterpret_cast<v4f *>(lds);
+        const v2f *__restrict__ lds2 = reinterpret_cast<const v2f *>(lds);
+        for (int cp0 = 0; cp0 < W * CPW; cp0 += cpp) {
+            const int ncp = min(cpp, W * CPW - cp0);
+            const int npieces = ncp * npc;
+            // range of each channel, storage order -> time order in LDS (row ci = rlen samples)
+            for (int i0 = 0; i0 < npieces; i0 += 4 * kWave * W) {
+                v4f v[4];
+                int dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = min(i0 + tid + kWave * W * u, npieces - 1);
+                    const int ci = (int)(((float)i + 0.5f) * a.rcp_npc);
+                    const int po = i - ci * npc;
+                    const int chc = min((cg * W + 0) * CPW + cp0 + ci, a.n_ch - 1);
+                    v[u] = *reinterpret_cast<const v4f *>(y2_out + (size_t)chc * a.y2_stride + a.y2_hist + base + 2 * po);
+                    const int o = 2 * po;                    // storage offset within the range: (body*SPW + segment)*Y2B + q
+                    const int body = o / (SPW * Y2B), seg = (o / Y2B) % SPW, q = o % Y2B;
+                    dst[u] = ci * rlen + seg * seg_y2 + body * Y2B + q;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (i0 + tid + kWave * W * u < npieces) lds4[dst[u] >> 1] = v[u];
+            }
+            __syncthreads();
+            if (n_int > 0) {
+                for (int ci = wave; ci < ncp; ci += W) {
+                    const int chn = cg * W * CPW + cp0 + ci;
+                    if (chn >= a.n_ch) break;
+                    float2 *__restrict__ y3row = y3_out + (size_t)chn * a.y3_stride;
+                    for (int k = lane; k < n_int; k += kWave) {
+                        const int rr = rr_lo + k;
+                        const v2f r = folded_fir_unrolled<TA>(lds2 + ci * rlen + (MA * rr + a.c0 - (TA - 1) - base), taps.h3);
+                        y3row[rr] = make_float2(r.x, r.y);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -600,41 +708,6 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
 // in time and in the body-major storage), one index computation per group.
 // MA == 0: chains with three stages (no stage A).
 // ------------------------------------------------------------------------------------------
-// acc += x * h[K] on both halves, the tap read from one half of an SGPR pair (op_sel picks the half): two taps per
-// pair instead of the (h, h) pair per tap the compiler would build -- 45 taps of the 10 MS/s tail would otherwise
-// need 90 SGPRs and spill into v_readlane/v_writelane traffic.  The s_nop is the wait state a packed op needs
-// when its source was written by the instruction right before it (hipcc cannot see into the asm).
-template <int K>
-__device__ __forceinline__ void fma_tap(v2f &acc, const v2f x, const v2f hpair)
-{
-    if constexpr ((K & 1) == 0)
-        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "s"(hpair));
-    else
-        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "s"(hpair));
-}
-
-template <int T, int I = 0>
-__device__ __forceinline__ void folded_fir_steps(v2f &acc, const v2f *__restrict__ w, const float (&h)[kMaxHalfTaps])
-{
-    constexpr int half = (T - 1) >> 1;
-    if constexpr (I <= half) {
-        const v2f hp = {h[I & ~1], h[(I & ~1) + 1]};
-        if constexpr (I < half)
-            fma_tap<I>(acc, w[I] + w[T - 1 - I], hp);
-        else
-            fma_tap<I>(acc, w[half], hp);
-        folded_fir_steps<T, I + 1>(acc, w, h);
-    }
-}
-
-template <int T>
-__device__ __forceinline__ v2f folded_fir_unrolled(const v2f *__restrict__ w, const float (&h)[kMaxHalfTaps])
-{
-    v2f acc = {0.f, 0.f};
-    folded_fir_steps<T>(acc, w, h);
-    return acc;
-}
-
 // group index (time j, a multiple of Y2B) -> index in the channel's body-major row
 __device__ __forceinline__ int y2_group_index(const TailArgs &a, int j)
 {
@@ -740,6 +813,103 @@ __global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
         if (a.iq_out) a.iq_out[(size_t)ch * a.out_stride + s0 + tid] = o;
         a.iq_keep[(size_t)ch * a.keep_stride + s0 + tid] = o;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tail4: what follows a k_stage12 with fused stage 3.  One workgroup per channel:
+//   * the call's stage-3 outputs [hist3 | interior outputs from y3] are staged in LDS;
+//   * the few stage-3 outputs per range boundary that k_stage12 left out (window across two workgroup ranges, or
+//     reaching into the previous call) are computed here from the stage-2 scratch / hist2 -- the same instruction
+//     sequence on the same operands as the interior ones, so the split into ranges never shows in a result;
+//   * last stage (MB, TB) -> iq_out / iq_keep, one lane per output, the reference's summation order;
+//   * hist2 / hist3 (the last H2 stage-2 / H3 stage-3 outputs of the stream) are rolled for the next call.
+// ------------------------------------------------------------------------------------------
+struct Tail4Args {
+    TailArgs t;              // y2_new, n_ch, y2_stride, n_y2_new, out/keep strides and pointers, n_b, body-major geometry (P == 1), hA, hB
+    const float2 *y3;        // [n_ch][y3_stride] interior stage-3 outputs of this call
+    float2 *hist2;           // [n_ch][H2]
+    float2 *hist3;           // [n_ch][H3]
+    int y3_stride, n_y3, c0; // stage-3 output rr: stage-2 window MA*rr + c0 - (TA-1) .. MA*rr + c0   (indices within the call)
+    int d0;                  // final output k: stage-3 window MB*k + d0 - (TB-1) .. MB*k + d0
+    int H2, H3;
+    int rlen, n_bnd;         // stage-2 outputs per workgroup range of k_stage12; range boundaries inside the call (incl. 0)
+};
+
+template <int MA, int TA, int MB, int TB>
+__global__ __launch_bounds__(256) void k_tail4(const Tail4Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const TailArgs &t = a.t;
+    const int ch = t.n_ch - 1 - blockIdx.x;                  // newest-written rows first (Infinity Cache)
+    const int tid = threadIdx.x;
+    const float2 *__restrict__ y2 = t.y2_new + (size_t)ch * t.y2_stride;
+    const float2 *__restrict__ y3 = a.y3 + (size_t)ch * a.y3_stride;
+    float2 *__restrict__ h2 = a.hist2 + (size_t)ch * a.H2;
+    float2 *__restrict__ h3 = a.hist3 + (size_t)ch * a.H3;
+    v4f *__restrict__ row4 = reinterpret_cast<v4f *>(smem);
+    v2f *__restrict__ row = reinterpret_cast<v2f *>(smem);   // row[H3 + rr] = stage-3 output rr of this call
+
+    // (1) every global load of the workgroup is issued before anything waits.
+    // boundary outputs: thread (bnd, u) takes the u-th stage-3 output whose window crosses stage-2 index bnd*rlen
+    const int bnd = tid >> 2;
+    const int B = bnd * a.rlen;
+    const int rr_s = (B - a.c0 + MA - 1) / MA + (tid & 3);
+    const int jn_s = MA * rr_s + a.c0;
+    const bool seam = bnd < a.n_bnd && rr_s < a.n_y3 && jn_s <= B + TA - 2;
+    static_assert((TA - 1 + MA - 1) / MA <= 4, "at most four stage-3 outputs per range boundary");
+    v2f sw[TA];
+    if (seam) {
+#pragma unroll
+        for (int i = 0; i < TA; i++) {
+            const int j = jn_s - (TA - 1) + i;
+            const float2 v = (j < 0) ? h2[a.H2 + j] : y2[y2_storage_index(t, j)];
+            sw[i] = v2f{v.x, v.y};
+        }
+    }
+    // the last H2 stage-2 outputs of the stream, for the next call's first boundary
+    float2 nh2 = make_float2(0.f, 0.f);
+    const int hi = tid - 128;
+    if (hi >= 0 && hi < a.H2) {
+        const int j = t.n_y2_new + hi - a.H2;
+        nh2 = (j < 0) ? h2[a.H2 + j] : y2[y2_storage_index(t, j)];
+    }
+    // (2) [hist3 | y3] -> LDS, 16-byte pieces (H3 is even: a piece never straddles the seam); one batch for a 32 ms block
+    const int npieces = (a.H3 + a.n_y3 + 1) >> 1;
+    constexpr int PU = 6;                                    // 256 x 6 pieces = 3 072 samples >= 80 + 2 561
+    for (int i0 = 0; i0 < npieces; i0 += 256 * PU) {
+        v4f pv[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const int p = min(i0 + tid + 256 * u, npieces - 1);
+            const float2 *src = (2 * p < a.H3) ? h3 + 2 * p : y3 + (2 * p - a.H3);
+            pv[u] = *reinterpret_cast<const v4f *>(src);
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++)
+            if (i0 + tid + 256 * u < npieces) row4[i0 + tid + 256 * u] = pv[u];
+    }
+    __syncthreads();
+    // (3) boundary outputs over the placeholders
+    if (seam) {
+        v2f acc = {0.f, 0.f};
+        folded_fir_steps<TA, kMaxHalfTaps>(acc, sw, t.hA);
+        row[a.H3 + rr_s] = acc;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (nh2: every read of the old hist2 is complete before anyone rewrites it)
+    __syncthreads();
+    // (4) last stage
+    for (int k = tid; k < t.n_b; k += 256) {
+        const v2f r = folded_fir_unrolled<TB>(row + a.H3 + MB * k + a.d0 - (TB - 1), t.hB);
+        const float2 o = make_float2(r.x, r.y);
+        if (t.iq_out) t.iq_out[(size_t)ch * t.out_stride + k] = o;
+        t.iq_keep[(size_t)ch * t.keep_stride + k] = o;
+    }
+    // (5) histories for the next call (every read of the old ones is behind the barriers above)
+    for (int i = tid; i < a.H3; i += 256) {
+        const v2f v = row[a.n_y3 + i];
+        h3[i] = make_float2(v.x, v.y);
+    }
+    if (hi >= 0 && hi < a.H2) h2[hi] = nh2;
 }
 
 // ------------------------------------------------------------------------------------------

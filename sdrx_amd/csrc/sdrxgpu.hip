@@ -101,9 +101,9 @@ extern "C" int sdrxgpu_make_translator(int N, int z, int ch_offset, sdrxgpu_iq *
 // ------------------------------------------------------------------------------------------
 struct K12Launch {
     const float2 *x, *tables;
-    float2 *y2;
+    float2 *y2, *y3;
     Stage12Args args;
-    const float *h1, *h2;
+    const float *h1, *h2, *h3;
     int W, CPW;
     int grid;
 };
@@ -119,16 +119,19 @@ static bool k12_geometry_compiled(int level, int W, int CPW)
     return W == 4 && CPW == 4;      // (4 waves x 4 channels: the only geometry whose two tile buffers fit 160 KB of LDS)
 }
 
-template <int M1, int T1, int M2, int T2, int Y2B, int LEVEL>
+// MA > 0: the variant with stage 3 (MA, TA) fused behind stages 1-2 (kernels.hpp, k_stage12)
+template <int M1, int T1, int M2, int T2, int Y2B, int LEVEL, int MA = 0, int TA = 1>
 static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
 {
-    Stage12Taps<T1, T2> taps;
+    Stage12Taps<T1, T2, TA> taps{};
     for (int i = 0; i < (T1 + 1) / 2; i++) taps.h1[i] = L.h1[i];
     for (int i = 0; i < (T2 + 1) / 2; i++) taps.h2[i] = L.h2[i];
+    if constexpr (MA > 0)
+        for (int i = 0; i < (TA + 1) / 2; i++) taps.h3[i] = L.h3[i];
 #define SDRX_K12_CASE(W_, C_)                                                                                  \
     if (L.W == W_ && L.CPW == C_) {                                                                             \
-        hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, W_, C_>), dim3(L.grid), dim3(64 * W_), 0, s, L.x,    \
-                           L.tables, L.y2, L.args, taps);                                                       \
+        hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, W_, C_, MA, TA>), dim3(L.grid), dim3(64 * W_), 0, s, \
+                           L.x, L.tables, L.y2, L.y3, L.args, taps);                                            \
         return hipGetLastError();                                                                               \
     }
     SDRX_K12_CASE(4, 4)
@@ -146,19 +149,22 @@ struct K12Entry {
     int M1, T1, M2, T2, Y2B;
     int level;
     k12_launch_fn fn;
+    // the chain's tail stages when stage 3 can run fused (fn_fused != nullptr): (MA, TA) inside k_stage12, (MB, TB) in k_tail4
+    int MA, TA, MB, TB;
+    k12_launch_fn fn_fused;
 };
 
 // one entry per first-two-stages pair of the reference's chains (sdrx.cpp:1588-1668)
 static const K12Entry k12_table[] = {
-    {5, 17, 5, 19, 4, 0, launch_k12<5, 17, 5, 19, 4, 0>},      // 10 MS/s    (sdrx.cpp:1660-1668)
-    {2, 9, 3, 13, 4, 0, launch_k12<2, 9, 3, 13, 4, 0>},        // 2.4 MS/s   (sdrx.cpp:1629-1637)
-    {3, 13, 4, 25, 4, 1, launch_k12<3, 13, 4, 25, 4, 1>},      // 0.96 MS/s  (sdrx.cpp:1589-1596)
-    {3, 13, 5, 19, 4, 1, launch_k12<3, 13, 5, 19, 4, 1>},      // 1.2 MS/s   (sdrx.cpp:1597-1604)
-    {3, 13, 6, 23, 4, 1, launch_k12<3, 13, 6, 23, 4, 1>},      // 1.44 MS/s  (sdrx.cpp:1605-1612)
-    {4, 15, 5, 19, 4, 1, launch_k12<4, 15, 5, 19, 4, 1>},      // 1.6 MS/s   (sdrx.cpp:1613-1620)
-    {4, 15, 6, 23, 4, 1, launch_k12<4, 15, 6, 23, 4, 1>},      // 1.92 MS/s  (sdrx.cpp:1621-1628)
-    {15, 53, 5, 21, 2, 2, launch_k12<15, 53, 5, 21, 2, 2>},    // 6 MS/s     (sdrx.cpp:1651-1658)
-    {20, 51, 4, 33, 2, 2, launch_k12<20, 51, 4, 33, 2, 2>},    // 2.56 MS/s  (sdrx.cpp:1641-1648; N % m != 0, sdrx.cpp:1642)
+    {5, 17, 5, 19, 4, 0, launch_k12<5, 17, 5, 19, 4, 0>, 5, 21, 5, 67, launch_k12<5, 17, 5, 19, 4, 0, 5, 21>},   // 10 MS/s    (sdrx.cpp:1660-1668)
+    {2, 9, 3, 13, 4, 0, launch_k12<2, 9, 3, 13, 4, 0>, 5, 19, 5, 45, launch_k12<2, 9, 3, 13, 4, 0, 5, 19>},       // 2.4 MS/s   (sdrx.cpp:1629-1637)
+    {3, 13, 4, 25, 4, 1, launch_k12<3, 13, 4, 25, 4, 1>, 0, 0, 0, 0, nullptr},      // 0.96 MS/s  (sdrx.cpp:1589-1596)
+    {3, 13, 5, 19, 4, 1, launch_k12<3, 13, 5, 19, 4, 1>, 0, 0, 0, 0, nullptr},      // 1.2 MS/s   (sdrx.cpp:1597-1604)
+    {3, 13, 6, 23, 4, 1, launch_k12<3, 13, 6, 23, 4, 1>, 0, 0, 0, 0, nullptr},      // 1.44 MS/s  (sdrx.cpp:1605-1612)
+    {4, 15, 5, 19, 4, 1, launch_k12<4, 15, 5, 19, 4, 1>, 0, 0, 0, 0, nullptr},      // 1.6 MS/s   (sdrx.cpp:1613-1620)
+    {4, 15, 6, 23, 4, 1, launch_k12<4, 15, 6, 23, 4, 1>, 0, 0, 0, 0, nullptr},      // 1.92 MS/s  (sdrx.cpp:1621-1628)
+    {15, 53, 5, 21, 2, 2, launch_k12<15, 53, 5, 21, 2, 2>, 0, 0, 0, 0, nullptr},    // 6 MS/s     (sdrx.cpp:1651-1658)
+    {20, 51, 4, 33, 2, 2, launch_k12<20, 51, 4, 33, 2, 2>, 0, 0, 0, 0, nullptr},    // 2.56 MS/s  (sdrx.cpp:1641-1648; N % m != 0, sdrx.cpp:1642)
 };
 
 static const K12Entry *find_k12(int M1, int T1, int M2, int T2)
@@ -206,6 +212,12 @@ struct sdrxgpu_bank {
     // device memory
     float2 *d_x = nullptr, *d_tables = nullptr, *d_y2 = nullptr, *d_keep = nullptr;
     float2 *d_y2b = nullptr;                  // second stage-2 scratch (pipelined mode only)
+    // stage 3 fused behind stages 1-2 (k_stage12<.., MA, TA> + k_tail4): interior stage-3 outputs of the call, and the
+    // last H2 stage-2 / H3 stage-3 outputs of the stream instead of d_hist
+    bool fused = false;
+    float2 *d_y3 = nullptr, *d_hist2 = nullptr, *d_hist3 = nullptr;
+    int H2 = 0, H3 = 0, y3_stride = 0;
+    size_t tail4_lds = 0;
     float2 *d_hist[2] = {nullptr, nullptr};   // stage-2 history, ping-pong between calls
     int hist_cur = 0;
     int tile_b = 64;                          // final outputs per k_tail workgroup (64: 8 workgroups per CU)
@@ -240,6 +252,7 @@ struct sdrxgpu_bank {
     struct TailJob {
         bool valid = false;
         TailArgs t;
+        int c0 = 0, n_y3 = 0, d0 = 0, n_bnd = 0;   // fused banks (Tail4Args)
         int roll_src = 0, roll_cnt = 0;   // input-history roll left for k_agc to do (serial mode)
     } pending;
     int y2_cur = 0;
@@ -288,6 +301,9 @@ static void free_bank(sdrxgpu_bank *b)
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     (void)hipFree(b->d_hist[0]);
     (void)hipFree(b->d_hist[1]);
+    (void)hipFree(b->d_y3);
+    (void)hipFree(b->d_hist2);
+    (void)hipFree(b->d_hist3);
     (void)hipFree(b->d_keep);
     (void)hipFree(b->d_audio_keep);
     (void)hipFree(b->d_state);
@@ -318,8 +334,14 @@ static int init_state(sdrxgpu_bank *b)
     b->y2_cur = 0;
     HIPCHK(hipMemsetAsync(b->d_x, 0, b->x_capacity * sizeof(float2), b->stream));
     HIPCHK(hipMemsetAsync(b->d_y2, 0, (size_t)b->n_ch * b->y2_stride * sizeof(float2), b->stream));
-    HIPCHK(hipMemsetAsync(b->d_hist[0], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
-    HIPCHK(hipMemsetAsync(b->d_hist[1], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
+    if (b->fused) {
+        HIPCHK(hipMemsetAsync(b->d_y3, 0, (size_t)b->n_ch * b->y3_stride * sizeof(float2), b->stream));
+        HIPCHK(hipMemsetAsync(b->d_hist2, 0, (size_t)b->n_ch * b->H2 * sizeof(float2), b->stream));
+        HIPCHK(hipMemsetAsync(b->d_hist3, 0, (size_t)b->n_ch * b->H3 * sizeof(float2), b->stream));
+    } else {
+        HIPCHK(hipMemsetAsync(b->d_hist[0], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
+        HIPCHK(hipMemsetAsync(b->d_hist[1], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
+    }
     b->hist_cur = 0;
     if (b->squelch) {
         HIPCHK(hipMemsetAsync(b->d_sql, 0, (size_t)b->n_ch * sizeof(uchar2), b->stream));   // SQL_CLOSED, sdrx.cpp:210
@@ -532,6 +554,33 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         b->P = b->bps / b->nb;
     }
 
+    // Stage 3 inside the stage-1/2 kernel: possible when the chain's tail is the compiled-in one, every
+    // workgroup covers one contiguous range of stage-2 outputs (P == 1) whose rows fit the LDS the tiles leave, and
+    // the call's range boundaries fit k_tail4's one pass (4 threads each).  Same outputs either way, bit for bit.
+    {
+        const int SPW = kWave / b->CPW;
+        const long long rlen = (long long)SPW * b->bps * k12->Y2B;
+        const size_t lds = 2 * (size_t)(SPW + b->W * b->CPW) * (b->SB * 8 + 16);
+        const long long n_bnd_max = (max_y2 + rlen - 1) / rlen;
+        const int max_y3 = k12->MA ? max_y2 / k12->MA + 2 : 0;
+        const size_t t4_lds = ((size_t)((k12->TB - 1 + 15) / 16) * 16 + max_y3 + 2) * sizeof(float2);   // k_tail4: [hist3 | y3] of one channel
+        const bool can = k12->fn_fused && cfg->n_stages == 4 && (int)b->m[2] == k12->MA && (int)b->ntaps[2] == k12->TA &&
+                         (int)b->m[3] == k12->MB && (int)b->ntaps[3] == k12->TB && b->P == 1 && !b->pipelined &&
+                         (size_t)rlen * sizeof(float2) <= lds && n_bnd_max <= 64 && !b->tail_generic && t4_lds <= 64 * 1024;
+        if (tune.fused_tail == 2 && !can) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.fused_tail = 2, but this bank cannot run stage 3 fused "
+                        "(chain tail, P = %d, pipelined = %d, range of %lld outputs vs %zu B of LDS)", b->P, (int)b->pipelined, rlen, lds);
+        }
+        b->fused = can && tune.fused_tail != 1;
+        if (b->fused) {
+            b->H2 = ((k12->TA - 1 + 15) / 16) * 16;
+            b->H3 = ((k12->TB - 1 + 15) / 16) * 16;
+            b->y3_stride = ((max_y3 + 63) / 64) * 64;
+            b->tail4_lds = t4_lds;
+        }
+    }
+
     if (cfg->stream) {
         b->stream = (hipStream_t)cfg->stream;
     } else {
@@ -558,8 +607,11 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         (rc = dev_alloc(b, (void **)&b->d_tables, 2 * (size_t)b->n_ch * b->tbl_stride * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_y2, (size_t)b->n_ch * b->y2_stride * sizeof(float2))) ||
         (b->pipelined && (rc = dev_alloc(b, (void **)&b->d_y2b, (size_t)b->n_ch * b->y2_stride * sizeof(float2)))) ||
-        (rc = dev_alloc(b, (void **)&b->d_hist[0], (size_t)b->n_ch * b->y2_hist * sizeof(float2))) ||
-        (rc = dev_alloc(b, (void **)&b->d_hist[1], (size_t)b->n_ch * b->y2_hist * sizeof(float2))) ||
+        (!b->fused && (rc = dev_alloc(b, (void **)&b->d_hist[0], (size_t)b->n_ch * b->y2_hist * sizeof(float2)))) ||
+        (!b->fused && (rc = dev_alloc(b, (void **)&b->d_hist[1], (size_t)b->n_ch * b->y2_hist * sizeof(float2)))) ||
+        (b->fused && (rc = dev_alloc(b, (void **)&b->d_y3, (size_t)b->n_ch * b->y3_stride * sizeof(float2)))) ||
+        (b->fused && (rc = dev_alloc(b, (void **)&b->d_hist2, (size_t)b->n_ch * b->H2 * sizeof(float2)))) ||
+        (b->fused && (rc = dev_alloc(b, (void **)&b->d_hist3, (size_t)b->n_ch * b->H3 * sizeof(float2)))) ||
         (rc = dev_alloc(b, (void **)&b->d_keep, (size_t)b->n_ch * b->keep_stride * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_audio_keep, (size_t)b->n_ch * b->keep_stride * sizeof(float))) ||
         (rc = dev_alloc(b, (void **)&b->d_state, (size_t)b->n_ch * sizeof(float4)))) {
@@ -766,6 +818,8 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
     info->samples_in = b->n_in;
     info->samples_out = b->n_out;
     info->device_bytes = b->device_bytes;
+    info->fused_tail = b->fused ? 1u : 0u;
+    info->reserved = 0;
     return SDRXGPU_OK;
 }
 
@@ -929,12 +983,37 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         if (x_need > b->x_capacity) return fail(SDRXGPU_ERR_HIP, "internal: input ring too small (%zu > %zu)", x_need, b->x_capacity);
         L.h1 = b->taps[0].data();
         L.h2 = b->taps[1].data();
+        L.h3 = nullptr;
+        L.y3 = nullptr;
         L.W = b->W;
         L.CPW = b->CPW;
         L.grid = a.n_cgx * a.n_wt;
+        a.y3_stride = 0;
+        a.c0 = 0;
+        a.n_y3 = 0;
+        a.rcp_npc = 0.f;
+        if (b->fused) {
+            // stage-3 output R (absolute) has stage-2 outputs MA*R + MA-1 - (TA-1) .. MA*R + MA-1 as its window
+            // (S::addSample fires on every MA-th input, msd.hpp:228-247); this call yields R = j0/MA .. j1/MA - 1
+            const long long r0 = j0 / k->MA, r1 = j1 / k->MA;
+            job->c0 = (int)(k->MA * r0 + k->MA - 1 - j0);
+            job->n_y3 = (int)(r1 - r0);
+            const long long q0 = r0 / k->MB;
+            job->d0 = (int)(k->MB * q0 + k->MB - 1 - r0);
+            const long long rlen = (long long)SPW * b->bps * k->Y2B;
+            job->n_bnd = (int)((n_y2_new + rlen - 1) / rlen);
+            L.h3 = b->taps[2].data();
+            L.y3 = b->d_y3;
+            a.y3_stride = b->y3_stride;
+            a.c0 = job->c0;
+            a.n_y3 = job->n_y3;
+            a.rcp_npc = 1.0f / (float)(rlen / 2);
+            if (job->n_y3 > b->y3_stride - 2 || job->n_bnd > 64)
+                return fail(SDRXGPU_ERR_HIP, "internal: %d stage-3 outputs / %d range boundaries exceed the fused path's buffers", job->n_y3, job->n_bnd);
+        }
         {
             ProfScope ps(b, SDRXGPU_K_STAGE12, st);
-            HIPCHK(k->fn(L, st));
+            HIPCHK((b->fused ? k->fn_fused : k->fn)(L, st));
         }
 
         // ---- parameters of the remaining stage(s) ----
@@ -1028,11 +1107,36 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     if (b->squelch && t.n_b != 512)
         return fail(SDRXGPU_ERR_UNSUPPORTED, "internal: squelch chunk of %d outputs", t.n_b);
     job->valid = false;
-    t.hist_in = b->d_hist[b->hist_cur];
-    t.hist_out = b->d_hist[b->hist_cur ^ 1];
     t.iq_out = d_iq_out ? d_iq_out + out_off : nullptr;
     t.out_stride = (int)out_stride;
-    {
+    if (b->fused) {
+        // boundary stage-3 outputs + last stage, one workgroup per channel (k_tail4)
+        Tail4Args f;
+        f.t = t;
+        f.y3 = b->d_y3;
+        f.hist2 = b->d_hist2;
+        f.hist3 = b->d_hist3;
+        f.y3_stride = b->y3_stride;
+        f.n_y3 = job->n_y3;
+        f.c0 = job->c0;
+        f.d0 = job->d0;
+        f.H2 = b->H2;
+        f.H3 = b->H3;
+        f.rlen = t.spw * t.seg_len;
+        f.n_bnd = job->n_bnd;
+        ProfScope ps(b, SDRXGPU_K_TAIL);
+        const size_t lds = ((size_t)b->H3 + job->n_y3 + 2) * sizeof(float2);
+        const K12Entry *k = b->k12;
+        if (k->MA == 5 && k->TA == 21 && k->MB == 5 && k->TB == 67)
+            hipLaunchKernelGGL((k_tail4<5, 21, 5, 67>), dim3(b->n_ch), dim3(256), lds, b->stream, f);
+        else if (k->MA == 5 && k->TA == 19 && k->MB == 5 && k->TB == 45)
+            hipLaunchKernelGGL((k_tail4<5, 19, 5, 45>), dim3(b->n_ch), dim3(256), lds, b->stream, f);
+        else
+            return fail(SDRXGPU_ERR_HIP, "internal: no k_tail4 for this chain");
+        HIPCHK(hipGetLastError());
+    } else {
+        t.hist_in = b->d_hist[b->hist_cur];
+        t.hist_out = b->d_hist[b->hist_cur ^ 1];
         ProfScope ps(b, SDRXGPU_K_TAIL);
         const dim3 grid(((b->n_ch + 7) / 8 * 8) * t.n_tiles);
         const int mA = t.has_a ? t.mA : 0, tA = t.has_a ? t.tA : 0;
@@ -1049,8 +1153,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             hipLaunchKernelGGL(k_tail, grid, dim3(256), b->tail_lds, b->stream, t);
 #undef SDRX_TAIL_CASE
         HIPCHK(hipGetLastError());
+        b->hist_cur ^= 1;
     }
-    b->hist_cur ^= 1;
 
     // ---- AGC -> |.| -> LF AGC ----
     if (t.n_b > 0) {
