@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsdrxgpu.so")
+# SDRXGPU_LIB_PATH: another build of the library (A/B measurements of kernel variants); default = the in-tree build
+LIB_PATH = os.environ.get("SDRXGPU_LIB_PATH") or os.path.join(_HERE, "lib", "libsdrxgpu.so")
 
 K_STAGE12, K_TAIL, K_AGC, K_TOTAL = 0, 1, 2, 3
 FLAG_LF_AGC_ACTIVE = 0x1

@@ -182,6 +182,46 @@ __device__ __forceinline__ v2f folded_fir_unrolled(const v2f *__restrict__ w, co
     return acc;
 }
 
+// Two outputs at once (windows w0 and w1, same taps): the two accumulation chains alternate, so neither packed FMA
+// reads the result of the instruction before it and one wait state serves both (fma_tap spends one per tap).  Per
+// output the same instruction sequence on the same operands as folded_fir_unrolled: bit-identical results.
+template <int K>
+__device__ __forceinline__ void fma_tap2(v2f &acc0, v2f &acc1, const v2f x0, const v2f x1, const v2f hpair)
+{
+    if constexpr ((K & 1) == 0)
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]"
+            : "+v"(acc0), "+v"(acc1) : "v"(x0), "v"(x1), "s"(hpair));
+    else
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+            : "+v"(acc0), "+v"(acc1) : "v"(x0), "v"(x1), "s"(hpair));
+}
+
+template <int T, int NH, int I = 0>
+__device__ __forceinline__ void folded_fir2_steps(v2f &acc0, v2f &acc1, const v2f *__restrict__ w0, const v2f *__restrict__ w1,
+                                                  const float (&h)[NH])
+{
+    static_assert(NH % 2 == 0 && NH >= (T + 1) / 2, "tap array: an even number of entries covering h[0 .. (T-1)/2]");
+    constexpr int half = (T - 1) >> 1;
+    if constexpr (I <= half) {
+        const v2f hp = {h[I & ~1], h[(I & ~1) + 1]};
+        if constexpr (I < half)
+            fma_tap2<I>(acc0, acc1, w0[I] + w0[T - 1 - I], w1[I] + w1[T - 1 - I], hp);
+        else
+            fma_tap2<I>(acc0, acc1, w0[half], w1[half], hp);
+        folded_fir2_steps<T, NH, I + 1>(acc0, acc1, w0, w1, h);
+    }
+}
+
+// Two outputs whose windows w0 and w1 both lie in LDS (any distance apart): nothing is shared between them but the
+// taps and the instruction slots -- the point is the alternating accumulation chains of fma_tap2.
+template <int T, int NH>
+__device__ __forceinline__ void folded_fir2_lds(v2f &r0, v2f &r1, const v2f *__restrict__ w0, const v2f *__restrict__ w1, const float (&h)[NH])
+{
+    r0 = v2f{0.f, 0.f};
+    r1 = v2f{0.f, 0.f};
+    folded_fir2_steps<T, NH>(r0, r1, w0, w1, h);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_stage12
 // ------------------------------------------------------------------------------------------
@@ -217,7 +257,7 @@ struct Stage12Args {
     int y3_stride;
     int c0;
     int n_y3;
-    float rcp_npc;          // 1 / (16-byte pieces of one workgroup range of one channel)
+    int seam_stride;        // float2 per channel of the seam buffer: [range][2][TA-1] (first / last TA-1 outputs of each range)
 };
 
 // LDS tile geometry.  A wave's 64 lanes are CPW channels x SPW = 64/CPW time segments (lane =
@@ -272,7 +312,7 @@ __device__ __forceinline__ void dma_row(const float2 *src_row /* wave-uniform */
 template <int M1, int T1, int M2, int T2, int Y2B, int W, int CPW, int MA = 0, int TA = 1>
 __global__ __launch_bounds__(kWave * W, (M1 > 6 ? 1 : 4))
 void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
-               float2 *__restrict__ y3_out, const Stage12Args a, const Stage12Taps<T1, T2, TA> taps)
+               float2 *__restrict__ y3_out, float2 *__restrict__ seam_out, const Stage12Args a, const Stage12Taps<T1, T2, TA> taps)
 {
     constexpr int SB = M1 * M2 * Y2B;                      // input samples per body
     constexpr int NY1 = M2 * Y2B;                          // stage-1 outputs per body
@@ -484,46 +524,65 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
         const int rr_lo = (base + (TA - 1) - a.c0 + MA - 1) / MA;
         const int rr_hi = (end - 1 - a.c0 >= 0) ? min((end - 1 - a.c0) / MA, a.n_y3 - 1) : -1;
         const int n_int = rr_hi - rr_lo + 1;
-        const int npc = rlen / 2;                            // 16-byte pieces per channel
+        const int npc = rlen / 2;                            // 16-byte pieces of one channel's range
         const int cpp = min(W * CPW, LDS_BYTES / (rlen * 8));    // channels per pass (host: >= 1)
         // every store of this workgroup's range has left its wave, and every wave is done with the tiles
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        v4f *__restrict__ lds4 = reinterpret_cast<v4f *>(lds);
         const v2f *__restrict__ lds2 = reinterpret_cast<const v2f *>(lds);
+        constexpr int NT = kWave * W;
+        const int n_half = (n_int + 1) >> 1;                 // a lane takes outputs kp and kp + n_half of one channel
+        const float rcp_half = __builtin_amdgcn_rcpf((float)max(n_half, 1));
+        const float rcp_seg = __builtin_amdgcn_rcpf((float)seg_y2);
+        const float2 *__restrict__ ysrc = y2_out + a.y2_hist + base;
         for (int cp0 = 0; cp0 < W * CPW; cp0 += cpp) {
             const int ncp = min(cpp, W * CPW - cp0);
-            const int npieces = ncp * npc;
-            // range of each channel, storage order -> time order in LDS (row ci = rlen samples)
-            for (int i0 = 0; i0 < npieces; i0 += 4 * kWave * W) {
-                v4f v[4];
-                int dst[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = min(i0 + tid + kWave * W * u, npieces - 1);
-                    const int ci = (int)(((float)i + 0.5f) * a.rcp_npc);
-                    const int po = i - ci * npc;
-                    const int chc = min((cg * W + 0) * CPW + cp0 + ci, a.n_ch - 1);
-                    v[u] = *reinterpret_cast<const v4f *>(y2_out + (size_t)chc * a.y2_stride + a.y2_hist + base + 2 * po);
-                    const int o = 2 * po;                    // storage offset within the range: (body*SPW + segment)*Y2B + q
-                    const int body = o / (SPW * Y2B), seg = (o / Y2B) % SPW, q = o % Y2B;
-                    dst[u] = ci * rlen + seg * seg_y2 + body * Y2B + q;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (i0 + tid + kWave * W * u < npieces) lds4[dst[u] >> 1] = v[u];
-            }
-            __syncthreads();
-            if (n_int > 0) {
-                for (int ci = wave; ci < ncp; ci += W) {
-                    const int chn = cg * W * CPW + cp0 + ci;
-                    if (chn >= a.n_ch) break;
-                    float2 *__restrict__ y3row = y3_out + (size_t)chn * a.y3_stride;
-                    for (int k = lane; k < n_int; k += kWave) {
-                        const int rr = rr_lo + k;
-                        const v2f r = folded_fir_unrolled<TA>(lds2 + ci * rlen + (MA * rr + a.c0 - (TA - 1) - base), taps.h3);
-                        y3row[rr] = make_float2(r.x, r.y);
+            const int chb = cg * W * CPW + cp0;              // first channel of this pass
+            // The range of each channel comes back by LDS-DMA, 1 KB per instruction, landing in TIME order (row ci =
+            // rlen samples): LDS piece d of a row (samples 2d, 2d+1) is fetched from where k_stage12 stored them,
+            // (body*SPW + segment)*Y2B + q.  A wave's lanes keep their source offset for all channels it fetches.
+            for (int d0 = 0; d0 < npc; d0 += kWave) {
+                const int d = min(d0 + lane, npc - 1);
+                const int tt = 2 * d;
+                const int seg = (int)(((float)tt + 0.5f) * rcp_seg);
+                const int rem = tt - seg * seg_y2;
+                const uint32_t soff = (uint32_t)((((rem / Y2B) * SPW + seg) * Y2B + (rem % Y2B)) * 8);
+                if (d0 + lane < npc) {
+                    for (int ci = wave; ci < ncp; ci += W) {
+                        const char *g = reinterpret_cast<const char *>(ysrc + (size_t)min(chb + ci, a.n_ch - 1) * a.y2_stride) + soff;
+                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)g, (lds_void *)(uint32_t)(uintptr_t)(lds + ((size_t)ci * rlen + 2 * d0) * 8),
+                                                         16, 0, 0);
                     }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // the first and the last TA-1 outputs of every range, compactly, for k_tail4's boundary outputs
+            {
+                constexpr int SE = 2 * (TA - 1);
+                for (int i = tid; i < ncp * SE; i += NT) {
+                    const int ci = i / SE, e = i - ci * SE;
+                    if (chb + ci < a.n_ch) {
+                        const v2f v = lds2[ci * rlen + (e < TA - 1 ? e : rlen - SE + e)];
+                        seam_out[(size_t)(chb + ci) * a.seam_stride + g * SE + e] = make_float2(v.x, v.y);
+                    }
+                }
+            }
+            // interior outputs: lane = (channel, kp), outputs kp and kp + n_half (conflict-free 40-byte lane stride)
+            const int n_work = (n_int > 0) ? ncp * n_half : 0;
+            for (int idx = tid; idx < n_work; idx += NT) {
+                const int ci = (int)(((float)idx + 0.5f) * rcp_half);
+                const int kp = idx - ci * n_half;
+                const int chn = chb + ci;
+                const bool second = kp + n_half < n_int;
+                const int rrA = rr_lo + kp, rrB = second ? rrA + n_half : rrA;
+                const v2f *__restrict__ wrow = lds2 + ci * rlen + (a.c0 - (TA - 1) - base);
+                v2f r0, r1;
+                folded_fir2_lds<TA>(r0, r1, wrow + MA * rrA, wrow + MA * rrB, taps.h3);
+                if (chn < a.n_ch) {
+                    float2 *__restrict__ y3row = y3_out + (size_t)chn * a.y3_stride;
+                    y3row[rrA] = make_float2(r0.x, r0.y);
+                    if (second) y3row[rrB] = make_float2(r1.x, r1.y);
                 }
             }
             __syncthreads();
@@ -827,6 +886,8 @@ __global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
 struct Tail4Args {
     TailArgs t;              // y2_new, n_ch, y2_stride, n_y2_new, out/keep strides and pointers, n_b, body-major geometry (P == 1), hA, hB
     const float2 *y3;        // [n_ch][y3_stride] interior stage-3 outputs of this call
+    const float2 *seam;      // [n_ch][seam_stride]: per range of k_stage12 its first and last TA-1 stage-2 outputs
+    int seam_stride;
     float2 *hist2;           // [n_ch][H2]
     float2 *hist3;           // [n_ch][H3]
     int y3_stride, n_y3, c0; // stage-3 output rr: stage-2 window MA*rr + c0 - (TA-1) .. MA*rr + c0   (indices within the call)
@@ -859,10 +920,15 @@ __global__ __launch_bounds__(256) void k_tail4(const Tail4Args a)
     static_assert((TA - 1 + MA - 1) / MA <= 4, "at most four stage-3 outputs per range boundary");
     v2f sw[TA];
     if (seam) {
+        // window j = jn_s - (TA-1) .. jn_s around B: below B the last TA-1 outputs of range bnd-1 (bnd 0: of the previous
+        // calls, hist2), from B on the first TA-1 outputs of range bnd
+        constexpr int SE = 2 * (TA - 1);
+        const float2 *__restrict__ sm = a.seam + (size_t)ch * a.seam_stride + bnd * SE;
+        const float2 *__restrict__ lo = (bnd == 0) ? h2 + a.H2 : sm;             // lo[j - B], j < B (range bnd-1's last TA-1 end right before sm)
 #pragma unroll
         for (int i = 0; i < TA; i++) {
-            const int j = jn_s - (TA - 1) + i;
-            const float2 v = (j < 0) ? h2[a.H2 + j] : y2[y2_storage_index(t, j)];
+            const int jr = jn_s - (TA - 1) + i - B;          // -(TA-1) .. TA-2
+            const float2 v = (jr < 0) ? lo[jr] : sm[jr];
             sw[i] = v2f{v.x, v.y};
         }
     }
@@ -897,12 +963,20 @@ __global__ __launch_bounds__(256) void k_tail4(const Tail4Args a)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (nh2: every read of the old hist2 is complete before anyone rewrites it)
     __syncthreads();
-    // (4) last stage
-    for (int k = tid; k < t.n_b; k += 256) {
-        const v2f r = folded_fir_unrolled<TB>(row + a.H3 + MB * k + a.d0 - (TB - 1), t.hB);
-        const float2 o = make_float2(r.x, r.y);
-        if (t.iq_out) t.iq_out[(size_t)ch * t.out_stride + k] = o;
-        t.iq_keep[(size_t)ch * t.keep_stride + k] = o;
+    // (4) last stage, two outputs per lane (k and k + 256: alternating accumulation chains, see fma_tap2)
+    const v2f *__restrict__ brow = row + a.H3 + a.d0 - (TB - 1);
+    for (int k = tid; k < t.n_b; k += 512) {
+        const bool second = k + 256 < t.n_b;
+        const int k2 = second ? k + 256 : k;
+        v2f r0, r1;
+        folded_fir2_lds<TB>(r0, r1, brow + MB * k, brow + MB * k2, t.hB);
+        const float2 o0 = make_float2(r0.x, r0.y), o1 = make_float2(r1.x, r1.y);
+        if (t.iq_out) {
+            t.iq_out[(size_t)ch * t.out_stride + k] = o0;
+            if (second) t.iq_out[(size_t)ch * t.out_stride + k2] = o1;
+        }
+        t.iq_keep[(size_t)ch * t.keep_stride + k] = o0;
+        if (second) t.iq_keep[(size_t)ch * t.keep_stride + k2] = o1;
     }
     // (5) histories for the next call (every read of the old ones is behind the barriers above)
     for (int i = tid; i < a.H3; i += 256) {
@@ -935,9 +1009,11 @@ struct AgcArgs {
     // per-channel modulation (k_agc<.., true> only): fm[c] != 0 -> FM demodulator, fm_prev = Demod::prev_sample
     const unsigned char *fm;
     float2 *fm_prev;
-    // input-history roll riding along as one extra block: x[roll_src .. +roll_cnt) -> x[0 ..) (roll_cnt <= 1024; 0: none)
-    float2 *roll_x;
-    int roll_src, roll_cnt;
+    // input-history roll riding along as one extra block: roll_from[0 .. roll_cnt) (the tail of the input ring this
+    // chunk was read from) -> roll_to[0 ..) (the head of the other ring); roll_cnt <= 1024, 0: none
+    const float2 *roll_from;
+    float2 *roll_to;
+    int roll_cnt;
 };
 
 struct AgcState {
@@ -997,21 +1073,10 @@ __device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const Ag
 template <bool SQ, bool FM>
 __global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
 {
-    // one extra block rolls the input history to the front of the ring for the next call (k_roll_history's
-    // job; riding along here saves a launch on the critical path): a single wave, all reads before all writes
+    // one extra block copies the input history to the front of the other input ring for the next call
+    // (k_roll_history's job; riding along here saves a launch on the critical path)
     if (a.roll_cnt > 0 && blockIdx.x == gridDim.x - 1) {
-        float2 v[1024 / kWave];
-#pragma unroll
-        for (int k = 0; k < 1024 / kWave; k++) {
-            const int i = threadIdx.x + kWave * k;
-            v[k] = i < a.roll_cnt ? a.roll_x[a.roll_src + i] : make_float2(0.f, 0.f);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 1024 / kWave; k++) {
-            const int i = threadIdx.x + kWave * k;
-            if (i < a.roll_cnt) a.roll_x[i] = v[k];
-        }
+        for (int i = threadIdx.x; i < a.roll_cnt; i += kWave) a.roll_to[i] = a.roll_from[i];
         return;
     }
     const int ch = blockIdx.x * kWave + threadIdx.x;
@@ -1315,14 +1380,11 @@ __global__ __launch_bounds__(256) void k_mix_out(const MixArgs a)
     reinterpret_cast<short2 *>(a.out_s16)[i] = make_short2(cvt(x0), cvt(x1));
 }
 
-// move x[src_off .. src_off+cnt) to x[0 .. cnt) (ranges may overlap; cnt <= blockDim.x = 1024)
-__global__ void k_roll_history(float2 *x, int src_off, int cnt)
+// input history -> head of the other input ring (cnt <= blockDim.x = 1024; the two rings never overlap)
+__global__ void k_roll_history(const float2 *__restrict__ from, float2 *__restrict__ to, int cnt)
 {
     const int i = threadIdx.x;
-    float2 v = make_float2(0.f, 0.f);
-    if (i < cnt) v = x[src_off + i];
-    __syncthreads();
-    if (i < cnt) x[i] = v;
+    if (i < cnt) to[i] = from[i];
 }
 
 }  // namespace sdrxgpu

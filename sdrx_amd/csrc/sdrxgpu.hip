@@ -101,7 +101,7 @@ extern "C" int sdrxgpu_make_translator(int N, int z, int ch_offset, sdrxgpu_iq *
 // ------------------------------------------------------------------------------------------
 struct K12Launch {
     const float2 *x, *tables;
-    float2 *y2, *y3;
+    float2 *y2, *y3, *seam;
     Stage12Args args;
     const float *h1, *h2, *h3;
     int W, CPW;
@@ -131,7 +131,7 @@ static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
 #define SDRX_K12_CASE(W_, C_)                                                                                  \
     if (L.W == W_ && L.CPW == C_) {                                                                             \
         hipLaunchKernelGGL((k_stage12<M1, T1, M2, T2, Y2B, W_, C_, MA, TA>), dim3(L.grid), dim3(64 * W_), 0, s, \
-                           L.x, L.tables, L.y2, L.y3, L.args, taps);                                            \
+                           L.x, L.tables, L.y2, L.y3, L.seam, L.args, taps);                                            \
         return hipGetLastError();                                                                               \
     }
     SDRX_K12_CASE(4, 4)
@@ -210,13 +210,17 @@ struct sdrxgpu_bank {
     int keep_stride = 0;
 
     // device memory
-    float2 *d_x = nullptr, *d_tables = nullptr, *d_y2 = nullptr, *d_keep = nullptr;
+    // two input rings [history | block | slack], used alternately: while the kernels of block k read ring k & 1, block
+    // k+1 may already be arriving (H2D copy, RCCL broadcast) in the other one; the history of block k is copied across
+    float2 *d_xr[2] = {nullptr, nullptr};
+    int xr = 0;                               // ring the NEXT chunk is read from
+    float2 *d_tables = nullptr, *d_y2 = nullptr, *d_keep = nullptr;
     float2 *d_y2b = nullptr;                  // second stage-2 scratch (pipelined mode only)
     // stage 3 fused behind stages 1-2 (k_stage12<.., MA, TA> + k_tail4): interior stage-3 outputs of the call, and the
     // last H2 stage-2 / H3 stage-3 outputs of the stream instead of d_hist
     bool fused = false;
-    float2 *d_y3 = nullptr, *d_hist2 = nullptr, *d_hist3 = nullptr;
-    int H2 = 0, H3 = 0, y3_stride = 0;
+    float2 *d_y3 = nullptr, *d_hist2 = nullptr, *d_hist3 = nullptr, *d_seam = nullptr;
+    int H2 = 0, H3 = 0, y3_stride = 0, seam_stride = 0;
     size_t tail4_lds = 0;
     float2 *d_hist[2] = {nullptr, nullptr};   // stage-2 history, ping-pong between calls
     int hist_cur = 0;
@@ -253,13 +257,15 @@ struct sdrxgpu_bank {
         bool valid = false;
         TailArgs t;
         int c0 = 0, n_y3 = 0, d0 = 0, n_bnd = 0;   // fused banks (Tail4Args)
-        int roll_src = 0, roll_cnt = 0;   // input-history roll left for k_agc to do (serial mode)
+        const float2 *roll_from = nullptr;   // input-history copy left for k_agc to do (serial mode)
+        float2 *roll_to = nullptr;
+        int roll_cnt = 0;
     } pending;
     int y2_cur = 0;
 
     // stream position
     uint64_t n_in = 0, n_out = 0;
-    long long x_origin = 0;          // absolute sample index held at d_x[0] (same parity as the next call's s0)
+    long long x_origin = 0;          // absolute sample index held at d_xr[xr][0] (same parity as the next call's s0)
 
     // profiling
     int prof = 0;                    // 0 off, 1 every kernel + whole call, 2 the stage-1/2 kernel only
@@ -289,7 +295,8 @@ static void free_bank(sdrxgpu_bank *b)
         (void)hipEventDestroy(s.b);
     }
     for (hipEvent_t e : b->pool) (void)hipEventDestroy(e);
-    (void)hipFree(b->d_x);
+    (void)hipFree(b->d_xr[0]);
+    (void)hipFree(b->d_xr[1]);
     (void)hipFree(b->d_tables);
     (void)hipFree(b->d_y2);
     (void)hipFree(b->d_y2b);
@@ -304,6 +311,7 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_y3);
     (void)hipFree(b->d_hist2);
     (void)hipFree(b->d_hist3);
+    (void)hipFree(b->d_seam);
     (void)hipFree(b->d_keep);
     (void)hipFree(b->d_audio_keep);
     (void)hipFree(b->d_state);
@@ -332,12 +340,15 @@ static int init_state(sdrxgpu_bank *b)
     if (b->stream2) HIPCHK(hipStreamSynchronize(b->stream2));
     b->pending.valid = false;
     b->y2_cur = 0;
-    HIPCHK(hipMemsetAsync(b->d_x, 0, b->x_capacity * sizeof(float2), b->stream));
+    HIPCHK(hipMemsetAsync(b->d_xr[0], 0, b->x_capacity * sizeof(float2), b->stream));
+    HIPCHK(hipMemsetAsync(b->d_xr[1], 0, b->x_capacity * sizeof(float2), b->stream));
+    b->xr = 0;
     HIPCHK(hipMemsetAsync(b->d_y2, 0, (size_t)b->n_ch * b->y2_stride * sizeof(float2), b->stream));
     if (b->fused) {
         HIPCHK(hipMemsetAsync(b->d_y3, 0, (size_t)b->n_ch * b->y3_stride * sizeof(float2), b->stream));
         HIPCHK(hipMemsetAsync(b->d_hist2, 0, (size_t)b->n_ch * b->H2 * sizeof(float2), b->stream));
         HIPCHK(hipMemsetAsync(b->d_hist3, 0, (size_t)b->n_ch * b->H3 * sizeof(float2), b->stream));
+        HIPCHK(hipMemsetAsync(b->d_seam, 0, (size_t)b->n_ch * b->seam_stride * sizeof(float2), b->stream));
     } else {
         HIPCHK(hipMemsetAsync(b->d_hist[0], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
         HIPCHK(hipMemsetAsync(b->d_hist[1], 0, (size_t)b->n_ch * b->y2_hist * sizeof(float2), b->stream));
@@ -577,6 +588,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             b->H2 = ((k12->TA - 1 + 15) / 16) * 16;
             b->H3 = ((k12->TB - 1 + 15) / 16) * 16;
             b->y3_stride = ((max_y3 + 63) / 64) * 64;
+            b->seam_stride = (int)(n_bnd_max + 1) * 2 * (k12->TA - 1);
             b->tail4_lds = t4_lds;
         }
     }
@@ -603,7 +615,8 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         b->x_capacity = (size_t)b->HIST + 2 + b->max_chunk + (size_t)G * SPW * b->spacing + (size_t)(b->WU + 2) * b->SB;
     }
     int rc;
-    if ((rc = dev_alloc(b, (void **)&b->d_x, b->x_capacity * sizeof(float2))) ||
+    if ((rc = dev_alloc(b, (void **)&b->d_xr[0], b->x_capacity * sizeof(float2))) ||
+        (rc = dev_alloc(b, (void **)&b->d_xr[1], b->x_capacity * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_tables, 2 * (size_t)b->n_ch * b->tbl_stride * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_y2, (size_t)b->n_ch * b->y2_stride * sizeof(float2))) ||
         (b->pipelined && (rc = dev_alloc(b, (void **)&b->d_y2b, (size_t)b->n_ch * b->y2_stride * sizeof(float2)))) ||
@@ -612,6 +625,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         (b->fused && (rc = dev_alloc(b, (void **)&b->d_y3, (size_t)b->n_ch * b->y3_stride * sizeof(float2)))) ||
         (b->fused && (rc = dev_alloc(b, (void **)&b->d_hist2, (size_t)b->n_ch * b->H2 * sizeof(float2)))) ||
         (b->fused && (rc = dev_alloc(b, (void **)&b->d_hist3, (size_t)b->n_ch * b->H3 * sizeof(float2)))) ||
+        (b->fused && (rc = dev_alloc(b, (void **)&b->d_seam, (size_t)b->n_ch * b->seam_stride * sizeof(float2)))) ||
         (rc = dev_alloc(b, (void **)&b->d_keep, (size_t)b->n_ch * b->keep_stride * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_audio_keep, (size_t)b->n_ch * b->keep_stride * sizeof(float))) ||
         (rc = dev_alloc(b, (void **)&b->d_state, (size_t)b->n_ch * sizeof(float4)))) {
@@ -826,7 +840,7 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
 extern "C" int sdrxgpu_bank_ingest_buffer(sdrxgpu_bank *b, void **d_ptr, size_t *capacity)
 {
     if (!b || !d_ptr) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_ingest_buffer: null argument");
-    *d_ptr = b->d_x + ((long long)b->n_in - b->x_origin);
+    *d_ptr = b->d_xr[b->xr] + ((long long)b->n_in - b->x_origin);
     if (capacity) *capacity = b->max_chunk;
     return SDRXGPU_OK;
 }
@@ -928,7 +942,7 @@ extern "C" int sdrxgpu_bank_profile_reset(sdrxgpu_bank *b)
 }
 
 // ------------------------------------------------------------------------------------------
-// one chunk (<= max_chunk samples, already at d_x + HIST) through the three kernels
+// one chunk (<= max_chunk samples, already in the current input ring behind its history) through the kernels
 // ------------------------------------------------------------------------------------------
 // outputs per channel that `len` samples arriving at stream position n0 yield (MSD::decimate's *out_len_ptr, msd.hpp:158)
 static size_t outputs_of(const sdrxgpu_bank *b, uint64_t n0, size_t len)
@@ -951,7 +965,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         Stage12Args &a = L.args;
         const long long s0 = j0 * b->MM;                               // abs index of the first input of y2[j0]
         const long long first = s0 - (long long)b->WU * b->SB;         // first warm-up sample of lane 0
-        L.x = b->d_x;
+        L.x = b->d_xr[b->xr];
         // translator entry met by input sample n: t[n mod N] on the mixer path (trans_pos_, msd.hpp:134-135);
         // with --ftfir stage 0's coefficient sets are laid out so that sample n meets t[(n - (m1-1)) mod N]
         // (msd.hpp:201-203: the set for output 0 starts at index N-(taps-1), its newest tap is t[0] on sample m1-1)
@@ -967,7 +981,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         a.y2_stride = b->y2_stride;
         a.y2_hist = 0;                                                 // new outputs start at row index 0
         a.n_y2_new = n_y2_new;
-        a.x_base = (int)(first - b->x_origin);                         // d_x[0] holds abs sample x_origin
+        a.x_base = (int)(first - b->x_origin);                         // the ring's entry 0 holds abs sample x_origin
         a.tphase0 = (int)(tph_abs - tcopy);
         a.nb = b->nb;
         a.P = b->P;
@@ -985,13 +999,14 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         L.h2 = b->taps[1].data();
         L.h3 = nullptr;
         L.y3 = nullptr;
+        L.seam = nullptr;
+        a.seam_stride = 0;
         L.W = b->W;
         L.CPW = b->CPW;
         L.grid = a.n_cgx * a.n_wt;
         a.y3_stride = 0;
         a.c0 = 0;
         a.n_y3 = 0;
-        a.rcp_npc = 0.f;
         if (b->fused) {
             // stage-3 output R (absolute) has stage-2 outputs MA*R + MA-1 - (TA-1) .. MA*R + MA-1 as its window
             // (S::addSample fires on every MA-th input, msd.hpp:228-247); this call yields R = j0/MA .. j1/MA - 1
@@ -1004,10 +1019,11 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
             job->n_bnd = (int)((n_y2_new + rlen - 1) / rlen);
             L.h3 = b->taps[2].data();
             L.y3 = b->d_y3;
+            L.seam = b->d_seam;
+            a.seam_stride = b->seam_stride;
             a.y3_stride = b->y3_stride;
             a.c0 = job->c0;
             a.n_y3 = job->n_y3;
-            a.rcp_npc = 1.0f / (float)(rlen / 2);
             if (job->n_y3 > b->y3_stride - 2 || job->n_bnd > 64)
                 return fail(SDRXGPU_ERR_HIP, "internal: %d stage-3 outputs / %d range boundaries exceed the fused path's buffers", job->n_y3, job->n_bnd);
         }
@@ -1077,17 +1093,21 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         const int cnt = (int)(n1 - origin_next);
         if (src_off < 0) return fail(SDRXGPU_ERR_HIP, "internal: history roll offset %d < 0", src_off);
         if (cnt > 1024) return fail(SDRXGPU_ERR_HIP, "internal: history roll of %d samples", cnt);
-        // serial mode: the roll rides along with k_agc of the same chunk (launch_tail), when there is one
-        job->roll_src = src_off;
-        job->roll_cnt = (src_off > 0) ? cnt : 0;
+        // the history goes to the head of the OTHER ring, which the next chunk is read from (its block may already be
+        // arriving there behind the history's place).  Serial mode: the copy rides along with k_agc of the same
+        // chunk (launch_tail), when there is one
+        job->roll_from = b->d_xr[b->xr] + src_off;
+        job->roll_to = b->d_xr[b->xr ^ 1];
+        job->roll_cnt = cnt;
         if (b->pipelined || !job->valid || job->t.n_b <= 0) {
             if (job->roll_cnt) {
-                hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(1024), 0, st, b->d_x, src_off, cnt);
+                hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(1024), 0, st, job->roll_from, job->roll_to, cnt);
                 HIPCHK(hipGetLastError());
             }
             job->roll_cnt = 0;
         }
         b->x_origin = origin_next;
+        b->xr ^= 1;
     }
     b->n_in += in_len;
     return SDRXGPU_OK;
@@ -1114,6 +1134,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         Tail4Args f;
         f.t = t;
         f.y3 = b->d_y3;
+        f.seam = b->d_seam;
+        f.seam_stride = b->seam_stride;
         f.hist2 = b->d_hist2;
         f.hist3 = b->d_hist3;
         f.y3_stride = b->y3_stride;
@@ -1180,8 +1202,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         fill(g.lf, b->lf);
         g.fm = b->d_fm;
         g.fm_prev = b->d_fm_prev;
-        g.roll_x = b->d_x;
-        g.roll_src = job->roll_src;
+        g.roll_from = job->roll_from;
+        g.roll_to = job->roll_to;
         g.roll_cnt = job->roll_cnt;
         job->roll_cnt = 0;
         const unsigned agc_blocks = (unsigned)((b->n_ch + kWave - 1) / kWave) + (g.roll_cnt > 0 ? 1u : 0u);
@@ -1331,7 +1353,7 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
     const float2 *src = (const float2 *)in;
     size_t done = 0, produced_total = 0;
     while (done < in_len) {
-        float2 *d_ingest = b->d_x + ((long long)b->n_in - b->x_origin);
+        float2 *d_ingest = b->d_xr[b->xr] + ((long long)b->n_in - b->x_origin);
         const size_t n = std::min(in_len - done, (size_t)b->max_chunk);
         if (in_is_host) {
             HIPCHK(hipMemcpyAsync(d_ingest, src + done, n * sizeof(float2), hipMemcpyHostToDevice, b->stream));

@@ -88,16 +88,16 @@ def test_fused_split_invariance_and_reset():
 
 
 def test_large_bank_runs_fused_by_default_and_matches_the_oracle(oracle):
-    """2 500 channels of the 10 MS/s chain: the automatic geometry is W=4, CPW=4, a whole segment per lane -> fused."""
+    """4 000 channels of the 10 MS/s chain: the automatic geometry is W=4, CPW=4, a whole segment per lane -> fused."""
     ch = chains.chain("10")
-    offs = chains.offsets_cycled(2500, ch.N)
+    offs = chains.offsets_cycled(4000, ch.N)
     tabs = sb.translators_for(ch, offs)
     L = ch.block_len
     blocks = [synth.synth_iq(77, b * L, L, 0.25, [tabs[700]], [0.2], ch.N, 10000) for b in range(2)]
     bank = sb.ChannelBank(tabs, ch.stage_tuples())
     assert bank.info().fused_tail == 1
     iq, au = _run(bank, blocks)
-    for c in (0, 1, 599, 600, 700, 1200, 2499):
+    for c in (0, 1, 599, 600, 700, 1200, 3999):
         ob = oracle.bank([tabs[c]], ch.stage_tuples())
         r = [ob.process(x, threads=1) for x in blocks]
         r_iq = np.concatenate([v[0] for v in r], axis=1)
