@@ -987,9 +987,15 @@ __global__ __launch_bounds__(256) void k_tail4(const Tail4Args a)
 }
 
 // ------------------------------------------------------------------------------------------
-// k_agc: lane = channel, strictly serial over the block's outputs (the only true recurrence
-// of the path: 512 dependent steps per channel per block).  Each lane streams its own row
-// (16-byte loads, 8 samples ahead), so no transposition is needed; 64 channels per wave.
+// k_agc: lane = channel, strictly serial over the block's outputs (the only true recurrence of the path: 512
+// dependent steps per channel per block).  What bounds it is not memory and not the dependency chain but ISSUE: a
+// wave that is alone on its SIMD issues one VALU instruction per 4 cycles, and one step of both loops is ~24
+// instructions.  So the two recurrences run on TWO waves (two SIMDs) of a 128-thread workgroup per 64 channels:
+//   wave 0: IF AGC (AGC::adjust, agc.hpp:48-69) over the decimated IQ; publishes |y|^2 (FM banks: y too) per
+//           sample through LDS, 8 samples at a time;
+//   wave 1: one chunk behind: envelope (or FM phase step), LF AGC (agc.hpp:106-131), squelch gating, audio out.
+// One barrier per 8 samples.  Each value is computed by the same expressions as before the split.
+// Each lane streams its own row (16-byte loads, 8 samples ahead), so no transposition is needed.
 // ------------------------------------------------------------------------------------------
 struct AgcParams {
     float attack, decay, reference, min_gain, max_gain, alpha;
@@ -1016,138 +1022,269 @@ struct AgcArgs {
     int roll_cnt;
 };
 
-struct AgcState {
-    float g, pw, gl, pl;
-};
+// AGC::adjust, agc.hpp:48-69, same operation order; returns y = x * gain-before-update through yr, yi and |y|^2.
+// a + b*c contracts to FMA here, as it does in the reference's own -march=native build; measured (round 1): a
+// contract(off) build is no closer to the portable golden vectors (the 1-ulp v_sqrt and the incoming IQ error
+// dominate) and 5 % slower.
+__device__ __forceinline__ void if_agc_step(const float2 x, float &g, float &pw, const AgcParams &A, float &yr, float &yi, float &nrm)
+{
+    // the FMAs are written out (and contraction is off) so that the instruction sequence does not depend on what the
+    // surrounding code looks like to the compiler: these are the contractions hipcc chose for the round-1 kernel
+#pragma clang fp contract(off)
+    yr = x.x * g;
+    yi = x.y * g;
+    nrm = __builtin_fmaf(yr, yr, yi * yi);
+    pw = __builtin_fmaf(A.alpha, nrm - pw, pw);
+    const float err = A.reference - pw;
+    g = __builtin_fmaf(err, err > 0.0f ? A.decay : A.attack, g);
+    g = __builtin_amdgcn_fmed3f(g, A.min_gain, A.max_gain);      // the clamp of agc.hpp:63-67 in one instruction
+}
 
 // mode: 0 = squelch closed (IF AGC only, silence), 1 = open, 2 = just opened (ramp_up), 3 = just closed (ramp_down).
-// Branch-free: this is a 512-step dependency chain, a branch per step would sit on its critical path.
-template <bool SQ, bool FM = false>
-__device__ __forceinline__ float agc_step(const float2 x, AgcState &st, const AgcParams &A, const AgcParams &Lf, int lf_active,
-                                          int mode = 1, float ramp = 1.0f, bool is_fm = false, float2 *fm_prev = nullptr)
+// Branch-free: a branch per step would sit on the loop's critical path.
+template <bool SQ, bool FM>
+__device__ __forceinline__ float demod_lf_step(float yr, float yi, float nrm, float &gl_, float &pl_, const AgcParams &Lf, int lf_active,
+                                               int mode, float ramp, bool is_fm, float2 &fm_prev)
 {
-    // AGC::adjust, agc.hpp:48-69, same operation order.  a + b*c contracts to FMA here, as it does in the reference's
-    // own -march=native build; measured (round 1): a contract(off) build is no closer to the portable golden vectors
-    // (the 1-ulp v_sqrt and the incoming IQ error dominate) and 5 % slower.
-    const float yr = x.x * st.g, yi = x.y * st.g;
-    const float nrm = yr * yr + yi * yi;
-    st.pw = st.pw + A.alpha * (nrm - st.pw);
-    const float err = A.reference - st.pw;
-    st.g = st.g + (err > 0.0f ? A.decay : A.attack) * err;
-    st.g = __builtin_amdgcn_fmed3f(st.g, A.min_gain, A.max_gain);      // the clamp of agc.hpp:63-67 in one instruction
-    // Demod::demod AM: std::abs, sdrx.cpp:178-180.  v_sqrt_f32 (1 ulp) instead of the correctly rounded
-    // software sequence: this loop is a 512-step dependency chain, its latency is the kernel's run time
+    // Demod::demod AM: std::abs, sdrx.cpp:178-180.  v_sqrt_f32 (1 ulp) instead of the correctly rounded software sequence
     float s = __builtin_amdgcn_sqrtf(nrm);
     if constexpr (FM) {
         // Demod::demod FM (EXPERIMENTAL in the reference, sdrx.cpp:181-194): phase step between consecutive
         // amplitude-normalised samples.  Called only while the squelch is open (sdrx.cpp:458-461); the ramp-down
         // chunk takes std::abs whatever the modulation (sdrx.cpp:499).  AM lanes of the same wave compute it too and
-        // drop it (no divergence in the 512-step chain).
+        // drop it (no divergence in the loop).
         const float i = yr / s, q = yi / s;                                 // complex<float> / float, sdrx.cpp:185
-        const float ph = atan2f(q * fm_prev->x - i * fm_prev->y, i * fm_prev->x + q * fm_prev->y);
+        const float ph = atan2f(q * fm_prev.x - i * fm_prev.y, i * fm_prev.x + q * fm_prev.y);
         const bool use = is_fm && (!SQ || mode == 1 || mode == 2);
-        fm_prev->x = use ? i : fm_prev->x;
-        fm_prev->y = use ? q : fm_prev->y;
+        fm_prev.x = use ? i : fm_prev.x;
+        fm_prev.y = use ? q : fm_prev.y;
         s = use ? ph : s;
     }
     // LfAGC::adjust, agc.hpp:106-131 -- only while the squelch is open or ramping down (sdrx.cpp:458-463, 498-501)
-    const float sl = s * st.gl;
-    const float pl = st.pl + Lf.alpha * (sl * sl - st.pl);
-    const float errl = Lf.reference - __builtin_amdgcn_sqrtf(pl);
-    float gl = st.gl + (errl > 0.0f ? Lf.decay : Lf.attack) * errl;
+    float pl, gl;
+    const float sl = s * gl_;
+    {
+#pragma clang fp contract(off)
+        pl = __builtin_fmaf(Lf.alpha, __builtin_fmaf(sl, sl, -pl_), pl_);   // (sl*sl - power is one rounding, as hipcc contracted it in round 1)
+        const float errl = Lf.reference - __builtin_amdgcn_sqrtf(pl);
+        gl = __builtin_fmaf(errl, errl > 0.0f ? Lf.decay : Lf.attack, gl_);
+    }
     gl = __builtin_amdgcn_fmed3f(gl, Lf.min_gain, Lf.max_gain);
     float out = lf_active ? sl : s;
     if constexpr (SQ) {
         const bool live = mode != 0;
-        st.pl = live ? pl : st.pl;
-        st.gl = live ? gl : st.gl;
+        pl_ = live ? pl : pl_;
+        gl_ = live ? gl : gl_;
         out = ramp * out;                     // ramp = ramp_up[i] / ramp_down[i] / 1 (open) / 0 (closed)
         return live ? out : 0.0f;
     } else {
-        st.pl = pl;
-        st.gl = gl;
+        pl_ = pl;
+        gl_ = gl;
         return out;
     }
 }
 
+constexpr int kAgcTile = 32;        // samples per tile (one barrier per tile)
+constexpr int kAgcIqPitch = kAgcTile + 2;    // float2 per channel row of an IQ tile: 272 B, conflict-free ds_read_b128 by lane = channel
+constexpr int kAgcAuPitch = kAgcTile + 4;    // floats per channel row of an audio tile: 144 B, conflict-free ds_write_b128
+
+template <bool FM>
+struct AgcLds {
+    float2 iq[3][kWave][kAgcIqPitch];                        // wave 2 fills tile t+2 while wave 0 reads tile t
+    float ex[2][kAgcTile][FM ? 3 : 1][kWave];                // wave 0 -> wave 1: |y|^2 (FM: and y) per sample, lane = channel
+    float au[2][kWave][kAgcAuPitch];                         // wave 1 -> wave 3
+};
+
+// Four waves (one per SIMD) per 64 channels, a software pipeline over tiles of 32 samples:
+//   wave 2  IQ rows, tile t+2: coalesced 16-byte loads (16 lanes per channel row) -> LDS.  (Each lane reading its own
+//           row straight from memory was the round-1 kernel: every load touched 64 different lines, and the address
+//           path, at 64 lines per instruction, made a step cost ~190 cycles.)
+//   wave 0  IF AGC on tile t (lane = channel), publishes |y|^2 through LDS
+//   wave 1  tile t-1: envelope (or FM phase step), LF AGC, squelch gating -> audio tile in LDS
+//   wave 3  tile t-2: audio tile -> coalesced stores
 template <bool SQ, bool FM>
-__global__ __launch_bounds__(kWave) void k_agc(const AgcArgs a)
+__global__ __launch_bounds__(4 * kWave) void k_agc(const AgcArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) char agc_smem[];
+    AgcLds<FM> &L = *reinterpret_cast<AgcLds<FM> *>(agc_smem);
     // one extra block copies the input history to the front of the other input ring for the next call
     // (k_roll_history's job; riding along here saves a launch on the critical path)
     if (a.roll_cnt > 0 && blockIdx.x == gridDim.x - 1) {
-        for (int i = threadIdx.x; i < a.roll_cnt; i += kWave) a.roll_to[i] = a.roll_from[i];
+        for (int i = threadIdx.x; i < a.roll_cnt; i += 4 * kWave) a.roll_to[i] = a.roll_from[i];
         return;
     }
-    const int ch = blockIdx.x * kWave + threadIdx.x;
-    if (ch >= a.n_ch) return;
-    const float2 *__restrict__ row = a.iq + (size_t)ch * a.iq_stride;
-    float *__restrict__ out = a.audio + (size_t)ch * a.out_stride;
-    const float4 s4 = a.state[ch];
-    AgcState st = {s4.x, s4.y, s4.z, s4.w};
-    bool is_fm = false;
-    float2 fmp = make_float2(0.f, 0.f);
-    if constexpr (FM) {
-        is_fm = a.fm[ch] != 0;
-        fmp = a.fm_prev[ch];
-    }
-    int mode = 1;
-    const float *__restrict__ ramp = a.ramp_down;
-    if constexpr (SQ) {
-        const uchar2 q = a.sql[ch];
-        mode = q.x ? (q.y ? 1 : 2) : (q.y ? 3 : 0);
-        ramp = (mode == 2) ? a.ramp_up : a.ramp_down;
-    }
-    const bool ramped = SQ && mode >= 2;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int ch0 = blockIdx.x * kWave;                      // first channel of this workgroup
+    const int chr = ch0 + lane;
+    const bool ok = chr < a.n_ch;                            // (lanes past the last channel work on the last row and store nothing)
+    const int ch = ok ? chr : a.n_ch - 1;
+    const int n_tiles = (a.n_out + kAgcTile - 1) / kAgcTile;
 
-    const int n8 = a.n_out & ~7;
-    const float4 *__restrict__ row4 = reinterpret_cast<const float4 *>(row);
-    float4 nx[4];
-    float4 nr[2];
-    if (n8 > 0) {
+    if (wave == 2) {
+        // ---- loader: tile t -> L.iq[t % 3]; instruction j covers channels 4j .. 4j+3, 16 lanes x 16 B per row ----
+        const int sub = lane >> 4, piece = lane & 15;
+        auto load_tile = [&](int t, v4f (&v)[16]) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) nx[k] = row4[k];
-        if constexpr (SQ) {
-            nr[0] = reinterpret_cast<const float4 *>(ramp)[0];
-            nr[1] = reinterpret_cast<const float4 *>(ramp)[1];
+            for (int j = 0; j < 16; j++) {
+                const int c = min(ch0 + 4 * j + sub, a.n_ch - 1);
+                const int smp = min(t * kAgcTile + 2 * piece, max(a.n_out - 1, 0) & ~1);   // (a piece past the row's end re-reads the last one)
+                v[j] = *reinterpret_cast<const v4f *>(a.iq + (size_t)c * a.iq_stride + smp);
+            }
+        };
+        auto put_tile = [&](int t, const v4f (&v)[16]) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) *reinterpret_cast<v4f *>(&L.iq[t % 3][4 * j + sub][2 * piece]) = v[j];
+        };
+        // tiles 0 and 1 before the pipeline starts; from then on the loads of tile i+4 are issued in iteration i and
+        // land in LDS in iteration i+2 (two iterations = ~1.5 us: a round trip to memory), two register sets in turn
+        v4f va[16], vb[16];
+        for (int t = 0; t < 2 && t < n_tiles; t++) {
+            load_tile(t, va);
+            put_tile(t, va);
         }
-    }
-    for (int base = 0; base < n8; base += 8) {
-        float4 cur[4];
-        float r[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int k = 0; k < 4; k++) cur[k] = nx[k];
-        if constexpr (SQ) {
-            if (ramped) {
-                r[0] = nr[0].x; r[1] = nr[0].y; r[2] = nr[0].z; r[3] = nr[0].w;
-                r[4] = nr[1].x; r[5] = nr[1].y; r[6] = nr[1].z; r[7] = nr[1].w;
+        if (2 < n_tiles) load_tile(2, va);
+        if (3 < n_tiles) load_tile(3, vb);
+        __syncthreads();
+        for (int i = 0; i < n_tiles + 2; i += 2) {
+            if (i + 2 < n_tiles) put_tile(i + 2, va);         // (buffer (i+2) % 3 was last read in iteration i-1)
+            if (i + 4 < n_tiles) load_tile(i + 4, va);
+            __syncthreads();
+            if (i + 1 < n_tiles + 2) {
+                if (i + 3 < n_tiles) put_tile(i + 3, vb);
+                if (i + 5 < n_tiles) load_tile(i + 5, vb);
+                __syncthreads();
             }
         }
-        if (base + 8 < n8) {
+    } else if (wave == 0) {
+        // ---- IF AGC ----
+        const float4 s4 = a.state[ch];
+        float g = s4.x, pw = s4.y;
+        __syncthreads();
+        // (a tile that lies wholly inside the call takes the branch-free body; only the last one can be short)
+        auto if_tile = [&](int i, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const v4f *__restrict__ row = reinterpret_cast<const v4f *>(&L.iq[i % 3][lane][0]);
 #pragma unroll
-            for (int k = 0; k < 4; k++) nx[k] = row4[(base + 8) / 2 + k];
-            if constexpr (SQ) {      // the ramp tables are 512 long = one chunk (n_out == 512 with squelch)
-                nr[0] = reinterpret_cast<const float4 *>(ramp)[((base + 8) & 511) / 4];
-                nr[1] = reinterpret_cast<const float4 *>(ramp)[((base + 8) & 511) / 4 + 1];
+            for (int k2 = 0; k2 < kAgcTile / 2; k2++) {
+                const v4f xx = row[k2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int k = 2 * k2 + h;
+                    if (FULL || i * kAgcTile + k < a.n_out) {
+                        float yr, yi, nrm;
+                        if_agc_step(h ? make_float2(xx.z, xx.w) : make_float2(xx.x, xx.y), g, pw, a.agc, yr, yi, nrm);
+                        L.ex[i & 1][k][0][lane] = nrm;
+                        if constexpr (FM) {
+                            L.ex[i & 1][k][1][lane] = yr;
+                            L.ex[i & 1][k][2][lane] = yi;
+                        }
+                    }
+                }
             }
+        };
+        for (int i = 0; i < n_tiles + 2; i++) {
+            if (i < n_tiles) {
+                if ((i + 1) * kAgcTile <= a.n_out) if_tile(i, std::true_type{});
+                else if_tile(i, std::false_type{});
+            }
+            __syncthreads();
         }
-        float y[8];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            y[2 * k + 0] = agc_step<SQ, FM>(make_float2(cur[k].x, cur[k].y), st, a.agc, a.lf, a.lf_active, mode, r[2 * k], is_fm, &fmp);
-            y[2 * k + 1] = agc_step<SQ, FM>(make_float2(cur[k].z, cur[k].w), st, a.agc, a.lf, a.lf_active, mode, r[2 * k + 1], is_fm, &fmp);
+        if (ok) reinterpret_cast<float2 *>(a.state + ch)[0] = make_float2(g, pw);
+    } else if (wave == 1) {
+        // ---- envelope / FM phase step -> LF AGC -> squelch gating, one tile behind wave 0 ----
+        const float4 s4 = a.state[ch];
+        float gl = s4.z, pl = s4.w;
+        bool is_fm = false;
+        float2 fmp = make_float2(0.f, 0.f);
+        if constexpr (FM) {
+            is_fm = a.fm[ch] != 0;
+            fmp = a.fm_prev[ch];
         }
-        if (a.audio_vec) {
-            reinterpret_cast<float4 *>(out + base)[0] = make_float4(y[0], y[1], y[2], y[3]);
-            reinterpret_cast<float4 *>(out + base)[1] = make_float4(y[4], y[5], y[6], y[7]);
-        } else {
+        int mode = 1;
+        const float *__restrict__ ramp = a.ramp_down;
+        if constexpr (SQ) {
+            const uchar2 q = a.sql[ch];
+            mode = q.x ? (q.y ? 1 : 2) : (q.y ? 3 : 0);
+            ramp = (mode == 2) ? a.ramp_up : a.ramp_down;
+        }
+        const bool ramped = SQ && mode >= 2;
+        __syncthreads();
+        auto lf_tile = [&](int t, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-            for (int k = 0; k < 8; k++) out[base + k] = y[k];
+            for (int k4 = 0; k4 < kAgcTile / 4; k4++) {
+                float y[4];
+                float4 r4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                if constexpr (SQ) {      // the ramp tables are 512 long = one chunk (n_out == 512 with squelch)
+                    if (ramped) r4 = reinterpret_cast<const float4 *>(ramp)[((t * kAgcTile + 4 * k4) & 511) / 4];
+                }
+                const float r[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const int k = 4 * k4 + h;
+                    y[h] = 0.f;
+                    if (FULL || t * kAgcTile + k < a.n_out) {
+                        const float nrm = L.ex[t & 1][k][0][lane];
+                        float yr = 0.f, yi = 0.f;
+                        if constexpr (FM) {
+                            yr = L.ex[t & 1][k][1][lane];
+                            yi = L.ex[t & 1][k][2][lane];
+                        }
+                        y[h] = demod_lf_step<SQ, FM>(yr, yi, nrm, gl, pl, a.lf, a.lf_active, mode, r[h], is_fm, fmp);
+                    }
+                }
+                *reinterpret_cast<float4 *>(&L.au[t & 1][lane][4 * k4]) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        };
+        for (int i = 0; i < n_tiles + 2; i++) {
+            const int t = i - 1;
+            if (t >= 0 && t < n_tiles) {
+                if ((t + 1) * kAgcTile <= a.n_out) lf_tile(t, std::true_type{});
+                else lf_tile(t, std::false_type{});
+            }
+            __syncthreads();
+        }
+        if (ok) {
+            reinterpret_cast<float2 *>(a.state + ch)[1] = make_float2(gl, pl);
+            if constexpr (FM) a.fm_prev[ch] = fmp;
+        }
+    } else {
+        // ---- storer: audio tile t-2 -> [ch][out_stride], 8 lanes x 16 B per row and instruction (or 4-byte stores) ----
+        __syncthreads();
+        for (int i = 0; i < n_tiles + 2; i++) {
+            const int t = i - 2;
+            if (t >= 0) {
+                const int s0 = t * kAgcTile;
+                if (a.audio_vec) {
+                    const int sub = lane >> 3, piece = lane & 7;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int cl = 8 * j + sub;
+                        const float4 v = *reinterpret_cast<const float4 *>(&L.au[t & 1][cl][4 * piece]);
+                        float *dst = a.audio + (size_t)(ch0 + cl) * a.out_stride + s0 + 4 * piece;
+                        if (ch0 + cl < a.n_ch) {
+                            if (s0 + 4 * piece + 4 <= a.n_out) {
+                                *reinterpret_cast<float4 *>(dst) = v;
+                            } else {
+                                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                for (int h = 0; h < 4; h++)
+                                    if (s0 + 4 * piece + h < a.n_out) dst[h] = e[h];
+                            }
+                        }
+                    }
+                } else {
+                    const int sub = lane >> 5, k = lane & 31;
+                    for (int j = 0; j < 32; j++) {
+                        const int cl = 2 * j + sub;
+                        if (ch0 + cl < a.n_ch && s0 + k < a.n_out) a.audio[(size_t)(ch0 + cl) * a.out_stride + s0 + k] = L.au[t & 1][cl][k];
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
-    for (int i = n8; i < a.n_out; i++) out[i] = agc_step<SQ, FM>(row[i], st, a.agc, a.lf, a.lf_active, mode, ramped ? ramp[i & 511] : 1.0f, is_fm, &fmp);
-    a.state[ch] = make_float4(st.g, st.pw, st.gl, st.pl);
-    if constexpr (FM) a.fm_prev[ch] = fmp;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -664,6 +664,16 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     }
 
     {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agc<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AgcLds<false>));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agc<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AgcLds<false>));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agc<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AgcLds<true>));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_agc<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AgcLds<true>));
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "hipFuncSetAttribute(k_agc) failed: %s", hipGetErrorString(e));
+        }
+    }
+    {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) {
             free_bank(b);
@@ -1213,13 +1223,13 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         ProfScope ps(b, SDRXGPU_K_AGC);
         if (b->squelch)
             if (b->d_fm)
-                hipLaunchKernelGGL((k_agc<true, true>), dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
+                hipLaunchKernelGGL((k_agc<true, true>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<true>), b->stream, g);
             else
-                hipLaunchKernelGGL((k_agc<true, false>), dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
+                hipLaunchKernelGGL((k_agc<true, false>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<false>), b->stream, g);
         else if (b->d_fm)
-            hipLaunchKernelGGL((k_agc<false, true>), dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
+            hipLaunchKernelGGL((k_agc<false, true>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<true>), b->stream, g);
         else
-            hipLaunchKernelGGL((k_agc<false, false>), dim3(agc_blocks), dim3(kWave), 0, b->stream, g);
+            hipLaunchKernelGGL((k_agc<false, false>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<false>), b->stream, g);
         HIPCHK(hipGetLastError());
         if (b->squelch) {
             SquelchArgs q;
