@@ -9,61 +9,142 @@ channels demodulated = million channel-samples per second, whole job.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--channels C]
 
-N > 1 is launched by the driver through torch.distributed.run, one rank per GPU: channels shard
-across ranks (weak scaling, C channel instances per GPU, no data-path collective); rank 0 owns the
-IQ stream and each step's block reaches the other GPUs by one RCCL broadcast (the only traffic
-over xGMI, 2.56 MB per 32 ms of signal).
+N > 1: one rank per GPU over RCCL.  Started as `python bench.py --gpus N` this process touches no GPU: it
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's JSON line
+and exits with the child's code.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment,
+as the driver does) it is a rank.  Channels shard across ranks (weak scaling, C channel instances per GPU, no
+data-path collective); rank 0 owns the IQ stream and block k+1 reaches the other GPUs by one RCCL broadcast
+(2.56 MB per 32 ms of signal, the only traffic over xGMI) into the banks' other input ring WHILE block k is
+being processed.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch  # first: libsdrxgpu then binds to the HIP runtime torch ships (one runtime per process)
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from sdrx_amd import bank as sb  # noqa: E402
-from sdrx_amd import chains, synth  # noqa: E402
-from sdrx_amd import dist as sdist  # noqa: E402
-
-FORCE_DIST = os.environ.get("SDRX_BENCH_FORCE_DIST") == "1"
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+FP32_PEAK_TF = 157.3      # MI355X fp32 vector peak (MI355X_MICROARCH.md; v_pk_fma_f32 / v_fma_f32 measure 116-123 TF in
+                          # tools/ubench_valu.hip with >= 2 waves per SIMD: profiles/r02_ubench_valu.txt)
+SETTLE_STEPS = 120
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--channels", type=int, default=10000, help="channel instances per GPU")
+    ap.add_argument("--rate", default="10")
+    ap.add_argument("--block-hint", type=int, default=0)
+    ap.add_argument("--fused", type=int, default=0, help="tuning.fused_tail: 0 auto, 1 separate tail kernel, 2 require the fused path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="SDRXGPU_FLAG_PIPELINED: call k returns block k-1 (measured: no gain, the two kernels compete for CUs)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the RCCL fan-out even with one rank (rehearsal of the N > 1 path on one GPU)")
+    ap.add_argument("--fanout", choices=("pipelined", "inline"), default="pipelined",
+                    help="A/B: broadcast of block k+1 beside the kernels of block k (default), or block k in line before its kernels")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="CPU-only check of the launcher and the fan-out: gloo ranks, no GPU, no channelizer work")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# parent mode: start the ranks
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`--gpus N` without a launcher around us: be the launcher.  This process never initialises a GPU (nothing
+    below imports torch.cuda state or loads libsdrxgpu); the ranks are fresh child processes."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_json = None
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            line_json = line.strip()
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if line_json:
+        print(line_json, flush=True)
+    sys.exit(rc if rc else (0 if line_json else 1))
+
+
+# ------------------------------------------------------------------------------------------------
+# accounting
+# ------------------------------------------------------------------------------------------------
 def algorithmic_bytes_per_channel_sample(m_total: int) -> float:
     """8 B read (one complex<float> in) + (8 + 4)/M B written (decimated IQ + audio)."""
     return 8.0 + 12.0 / m_total
 
 
-def cpu_baseline(chain, seconds=12.0):
-    """Reference CPU path timed on this box's host cores on a bounded sample of the same workload.
+def flops_per_channel_sample(chain, n_stages):
+    """fp32 flop per input sample of one channel, as the reference's folded FIR does them (msd.hpp:309-332): mixer =
+    one complex multiply (6); a stage of T taps, half = (T-1)/2: (half pair sums + (half+1) products + (half+1)
+    accumulations) x 2 parts per output, one output per prod(m) input samples."""
+    total, dec = 6.0, 1
+    for st in chain.stages[:n_stages]:
+        half = (len(st.h) - 1) // 2
+        dec *= st.m
+        total += 2.0 * (half + 2 * (half + 1)) / dec
+    return total
 
-    Uses the compiled reference (oracle/_ref, kind 'reference') when that build travelled here, else
-    the oracle's -O3 build of the C restatement (kind 'port').  This is the ONLY place bench.py touches oracle/."""
+
+def profile_facts(n_ch, fused):
+    """HBM bytes per k_stage12 launch and the clock the chip sustains, from the rocprofv3 --pmc passes of this build
+    (tools_pmc.sh -> profiles/*_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    None when no profile of this channel count / kernel path is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("channels") == n_ch and bool(d.get("fused_tail", False)) == bool(fused):
+                return d, os.path.basename(f)
+        except (OSError, ValueError):
+            pass
+    return None, None
+
+
+def cpu_baseline(chain, seconds=12.0):
+    """The oracle's C restatement of the reference CPU path (kind "port": oracle/sdrx_oracle.c built -O3 -march=native,
+    bit-identical to the compiled reference on every golden vector), timed on this box's host cores on a bounded sample
+    of the same workload.  When the compiled reference itself travelled here (oracle/_ref, git-ignored) it is timed
+    too and reported under "reference_build".  This is the ONLY place bench.py touches oracle/."""
     from oracle import ffi
-    kind = "port"
-    lib = None
+    from sdrx_amd import chains, synth
+    ffi.build(ref=False)
+    libs = [("port", ffi.load("oracle_fast"))]
     if ffi.have_ref() and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsdrx_ref_avx2.so")):
         try:
-            lib = ffi.load("ref_avx2")
-            kind = "reference"
+            libs.append(("reference", ffi.load("ref_avx2")))
         except OSError:
-            lib = None
-    if lib is None:
-        ffi.build(ref=False)
-        lib = ffi.load("oracle_fast")
+            pass
     n_thr = max(1, min(len(os.sched_getaffinity(0)), 64))
     n_ch = 16 * n_thr
     offs = chains.offsets_cycled(n_ch, chain.N)
-    hlp = ffi.load("oracle") if kind == "port" else lib
+    hlp = ffi.load("oracle")
     tabs = [hlp.make_translator(chain.N, chain.z, o) if o else None for o in offs]
     x = synth.synth_iq(1, 0, chain.block_len, 0.25)
 
-    def run(threads, n_channels, budget):
+    def run(lib, threads, n_channels, budget):
         b = lib.bank(tabs[:n_channels], chain.stage_tuples())
         b.process(x, threads=threads)           # warm-up block
         t0 = time.perf_counter()
@@ -76,44 +157,102 @@ def cpu_baseline(chain, seconds=12.0):
         dt = time.perf_counter() - t0
         return n_channels * chain.block_len * blocks / dt, blocks
 
-    multi, nb_m = run(n_thr, n_ch, seconds * 0.6)
-    single, nb_s = run(1, 16, seconds * 0.4)
-    return {
-        "value": multi / 1e6, "unit": "Mch-samples/s", "cores": n_thr, "kind": kind,
-        "sample": f"{n_ch} channels x {nb_m} blocks of {chain.block_len} samples, one thread per channel range "
-                  f"(reference -t/DS model); single thread on 16 channels x {nb_s} blocks: {single / 1e6:.1f} Mch-samples/s",
-        "single_core_value": single / 1e6,
-    }
+    share = seconds / len(libs)
+    res = {}
+    for kind, lib in libs:
+        multi, nb_m = run(lib, n_thr, n_ch, share * 0.6)
+        single, nb_s = run(lib, 1, 16, share * 0.4)
+        res[kind] = {"value": multi / 1e6, "unit": "Mch-samples/s", "cores": n_thr, "kind": kind,
+                     "sample": f"{n_ch} channels x {nb_m} blocks of {chain.block_len} samples, one thread per channel range "
+                               f"(reference -t/DS model); single thread on 16 channels x {nb_s} blocks: {single / 1e6:.1f} Mch-samples/s",
+                     "single_core_value": single / 1e6}
+    out = res["port"]
+    if "reference" in res:
+        out["reference_build"] = res["reference"]
+    return out
 
 
-SETTLE_STEPS = 120
+# ------------------------------------------------------------------------------------------------
+# launcher / fan-out self-test (CPU, gloo)
+# ------------------------------------------------------------------------------------------------
+def selftest_launch(args):
+    """What `--gpus N` does around the channelizer, without a GPU: N gloo ranks, the double-buffered fan-out of the
+    IQ blocks, the barrier / max-over-ranks timing and rank 0's JSON line.  No channelizer work (value = 0)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sdrx_amd import dist as sdist
+    from sdrx_amd import synth
+    rank, _, world = sdist.env_rank_world()
+    dist.init_process_group("gloo")
+    L = 4096
+    bufs = [torch.empty(L, 2), torch.empty(L, 2)]
+    fan = sdist.PipelinedFanout(dist, bufs, src=0)
+
+    def block(k):
+        return torch.from_numpy(synth.synth_iq(7, k * L, L, 0.25).view(np.float32).reshape(L, 2).copy())
+
+    steps = args.steps
+    fan.post(0, block(0) if rank == 0 else None)
+    dist.barrier()
+    t0 = time.perf_counter()
+    bad = 0
+    for k in range(steps):
+        cur = fan.get(k)
+        if k + 1 < steps:
+            fan.post(k + 1, block(k + 1) if rank == 0 else None)
+        bad += int(not torch.equal(cur, block(k)))           # every rank regenerates the block it should have received
+        fan.done(k)
+    dist.barrier()
+    dt = sdist.max_over_ranks(dist, time.perf_counter() - t0)
+    t = torch.tensor([bad], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"metric": "IQ Msamples/s ingested x channels demodulated (channel-samples/s)", "value": 0.0,
+                          "unit": "Mch-samples/s", "n_gpus": world, "steps": steps, "warmup": 0, "ms_per_step": dt / steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "selftest: launcher + double-buffered block fan-out only (gloo, CPU)",
+                                     "parallelism": f"{world} gloo ranks"},
+                          "selftest": {"blocks_received_wrong": int(t.item())}}), flush=True)
+    dist.destroy_process_group()
+    sys.exit(1 if int(t.item()) else 0)
 
 
-def time_bank(bank, fan, ring, rank, world, dist, L, d_iq, d_au, steps, warmup, n_ring):
-    """W untimed warm-up steps, then exactly `steps` timed steps bracketed by synchronize + barrier."""
-    def step(i):
-        src = ring[i % n_ring] if rank == 0 else None
-        cur = fan.step(src, force=FORCE_DIST)  # N > 1: RCCL broadcast over xGMI of the shared IQ block
+# ------------------------------------------------------------------------------------------------
+# rank mode
+# ------------------------------------------------------------------------------------------------
+def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch):
+    """SETTLE + W untimed steps, then exactly `steps` timed steps bracketed by synchronize + barrier."""
+    state = {"k": 0}
+
+    def block_for(k):
+        return ring[k % n_ring] if rank == 0 else None
+
+    fan.post(0, block_for(0))
+
+    def step():
+        k = state["k"]
+        cur = fan.get(k)                      # N > 1: the compute stream waits for block k's broadcast (issued a step ago)
+        fan.post(k + 1, block_for(k + 1))     # block k+1 starts moving into the bank's other input ring
         n = bank.process_device(cur.data_ptr(), L, d_iq.data_ptr(), d_au.data_ptr(), 512)
-        assert n == 512 or (i == 0 and n == 0)      # a pipelined bank returns block k-1 at call k
+        fan.done(k)
+        assert n == 512 or (k == 0 and n == 0)      # a pipelined bank returns block k-1 at call k
+        state["k"] = k + 1
 
     # Clock settling, untimed and in front of the W warm-up steps: from idle the chip needs ~50 ms of this load before
     # its clock is steady (measured per step: 1.24, 1.35, 1.61, 1.52, ... 1.22 at step 12, 1.15 from step ~40 on).
     # A fixed number of steps, the same on every rank (each step is a collective when N > 1).
-    for i in range(SETTLE_STEPS):
-        step(i)
-    for i in range(warmup):
-        step(SETTLE_STEPS + i)
+    for _ in range(SETTLE_STEPS + warmup):
+        step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    warmup += SETTLE_STEPS           # (ring index of the timed steps below)
     bank.profile_reset()
     bank.profile_enable(2)      # HIP events around the dominant kernel only (roofline.achieved comes from the timed region)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        step(warmup + i)
+    for _ in range(steps):
+        step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -125,9 +264,8 @@ def time_bank(bank, fan, ring, rank, world, dist, L, d_iq, d_au, steps, warmup, 
     # the smaller kernels: a few more steps after the timed region, every kernel bracketed
     bank.profile_reset()
     bank.profile_enable(1)
-    extra = min(5, steps)
-    for i in range(extra):
-        step(warmup + steps + i)
+    for _ in range(min(5, steps)):
+        step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -135,50 +273,35 @@ def time_bank(bank, fan, ring, rank, world, dist, L, d_iq, d_au, steps, warmup, 
         ms, n = bank.profile_read(kid)
         k[name] = (ms / max(n, 1), int(n))
     bank.profile_enable(0)
+    fan.get(state["k"])          # drain the broadcast that is still in flight
+    torch.cuda.synchronize()
     return dt, k
 
 
-def measured_traffic(n_ch):
-    """HBM bytes per k_stage12 launch from the rocprofv3 --pmc passes of this build (tools_pmc.sh ->
-    profiles/*_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  null when no
-    profile of this channel count is committed."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
-        try:
-            d = json.load(open(f))
-            if d.get("channels") == n_ch:
-                return d.get("k_stage12_hbm_bytes_per_launch"), os.path.basename(f)
-        except (OSError, ValueError):
-            pass
-    return None, None
-
-
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--channels", type=int, default=10000, help="channel instances per GPU")
-    ap.add_argument("--rate", default="10")
-    ap.add_argument("--block-hint", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-configs", action="store_true")
-    ap.add_argument("--pipelined", action="store_true",
-                    help="SDRXGPU_FLAG_PIPELINED: call k returns block k-1 (measured: no gain, the two kernels compete for CUs)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    args = parse_args()
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        spawn_ranks(args)                   # does not return
+    if args.selftest_launch:
+        selftest_launch(args)               # does not return
+
+    import numpy as np
+    import torch  # before libsdrxgpu: it then binds to the HIP runtime torch ships (one runtime per process)
+    from sdrx_amd import bank as sb
+    from sdrx_amd import chains, synth
+    from sdrx_amd import dist as sdist
 
     rank, local_rank, world = sdist.env_rank_world()
-    if world != args.gpus and world > 1:
+    if world > 1:
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
-    force_dist = os.environ.get("SDRX_BENCH_FORCE_DIST") == "1"     # rehearse the RCCL path with a single rank
-    if world > 1 or force_dist:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
-        if force_dist and world == 1:
+        if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -186,33 +309,38 @@ def main():
     ch = chains.chain(args.rate)
     n_ch = args.channels
     L = ch.block_len
-    # one explicit (non-default) torch stream carries everything: the ring copy, the RCCL broadcast and the
-    # bank's kernels are then ordered by stream order alone
+    # one explicit (non-default) torch stream carries the bank's kernels and the ring copies; the RCCL broadcast of
+    # the NEXT block runs on the fan-out's own stream beside them
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
 
     # synthetic IQ stream: a ring of distinct 32 ms blocks in HBM on rank 0 (uniform noise + 2 AM carriers)
     n_ring = 8
-    blk = torch.empty(L, 2, dtype=torch.float32, device="cuda")
     ring = None
     if rank == 0:
         car = [sb.make_translator(ch.N, ch.z, o) for o in (5, -20)]
         host = np.stack([synth.synth_iq(1234, b * L, L, 0.25, car, [0.3, 0.1], ch.N, ch.fs // 1000).view(np.float32).reshape(L, 2)
                          for b in range(n_ring)])
         ring = torch.from_numpy(host).cuda()
+
+    tuning = {"fused_tail": args.fused} if args.fused else None
+    fused_seen = {}
+
     def run(offsets, steps, warmup):
         tabs = sb.translators_for(ch, offsets)
         bank = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, stream=tstream.cuda_stream, block_hint=args.block_hint,
-                              pipelined=args.pipelined)
-        # N > 1: the broadcast lands directly in the bank's ingest buffer (its address is the same for every whole
-        # block), so process_device finds the block in place; should the address ever differ the call copies
-        ing_ptr, ing_cap = bank.ingest_buffer()
-        recv = torch.as_tensor(sb.DeviceView(ing_ptr, (L, 2)), device="cuda") if ing_cap >= L else blk
-        fan = sdist.BlockFanout(dist, recv, src=0)
+                              pipelined=args.pipelined, tuning=tuning)
+        fused_seen[len(offsets)] = int(bank.info().fused_tail)
+        # N > 1: the broadcasts land directly in the bank's two input rings, alternately (their addresses repeat
+        # for whole blocks), so process_device finds each block in place; any other address would be copied in
+        p0, cap = bank.ingest_buffer()
+        p1 = bank.ingest_buffer_after(L)
+        recv = [torch.as_tensor(sb.DeviceView(p, (L, 2)), device="cuda") for p in (p0, p1)]
+        fan = sdist.PipelinedFanout(dist, recv, src=0, force=args.force_dist, inline=args.fanout == "inline")
         d_iq = torch.empty(len(offsets), 512, 2, dtype=torch.float32, device="cuda")
         d_au = torch.empty(len(offsets), 512, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
-        dt, k = time_bank(bank, fan, ring, rank, world, dist, L, d_iq, d_au, steps, warmup, n_ring)
+        dt, k = time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch)
         if args.pipelined:
             assert bank.flush(d_iq.data_ptr(), d_au.data_ptr(), 512) == 512
             torch.cuda.synchronize()
@@ -224,6 +352,7 @@ def main():
     offs = sdist.shard_list(chains.offsets_cycled(n_ch * world, ch.N), rank, world)
     assert len(offs) == n_ch
     dt, k = run(offs, args.steps, args.warmup)
+    fused = fused_seen[n_ch]
 
     extra = {}
     if world == 1 and not args.no_extra_configs:
@@ -233,38 +362,36 @@ def main():
             dte, ke = run(o, max(10, args.steps), args.warmup)
             extra[name] = {"value": len(o) * L * max(10, args.steps) / dte / 1e6, "unit": "Mch-samples/s",
                            "ms_per_step": dte / max(10, args.steps) * 1e3, "realtime_factor": L * max(10, args.steps) / dte / ch.fs,
-                           "kernel_ms_avg": {n: v[0] for n, v in ke.items()}}
+                           "kernel_ms_avg": {n: v[0] for n, v in ke.items()}, "fused_tail": fused_seen[len(o)]}
 
     if world == 1 and not args.no_extra_configs:
         # BASELINE configs[4], one GPU's share: 2 independent 10 MS/s streams x 1024 channels, each stream's block
-        # arriving from pinned host memory by an async H2D copy on the bank's own stream (copy overlaps the other
-        # stream's kernels)
+        # arriving from pinned host memory: sdrxgpu_bank_process_pinned enqueues the H2D copy into the bank's free input
+        # ring on the bank's copy stream and the kernels behind it, and returns without waiting
         n_streams, o = 2, chains.offsets_for_config("c3")
         tabs = sb.translators_for(ch, o)
-        sts = [torch.cuda.Stream() for _ in range(n_streams)]
-        banks = [sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, stream=st.cuda_stream) for st in sts]
+        banks = [sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank) for _ in range(n_streams)]
         hosts = [torch.from_numpy(synth.synth_iq(1 + i, 0, L, 0.25).view(np.float32).reshape(L, 2).copy()).pin_memory() for i in range(n_streams)]
-        ing = [torch.as_tensor(sb.DeviceView(bk.ingest_buffer()[0], (L, 2)), device="cuda") for bk in banks]
         outs = [(torch.empty(len(o), 512, 2, device="cuda"), torch.empty(len(o), 512, device="cuda")) for _ in range(n_streams)]
 
         def multi_step():
             for i in range(n_streams):
-                with torch.cuda.stream(sts[i]):
-                    ing[i].copy_(hosts[i], non_blocking=True)
-                    banks[i].process_device(ing[i].data_ptr(), L, outs[i][0].data_ptr(), outs[i][1].data_ptr(), 512)
+                banks[i].process_pinned(hosts[i].data_ptr(), L, outs[i][0].data_ptr(), outs[i][1].data_ptr(), 512)
 
-        for _ in range(args.warmup):
+        for _ in range(args.warmup + 20):
             multi_step()
-        torch.cuda.synchronize()
+        for bk in banks:
+            bk.synchronize()
         n_it = max(10, args.steps)
         t0 = time.perf_counter()
         for _ in range(n_it):
             multi_step()
-        torch.cuda.synchronize()
+        for bk in banks:
+            bk.synchronize()
         dtm = time.perf_counter() - t0
         extra["2 streams x 1024 channels, H2D from pinned host overlapped (configs[4] per GPU)"] = {
             "value": n_streams * len(o) * L * n_it / dtm / 1e6, "unit": "Mch-samples/s", "ms_per_step": dtm / n_it * 1e3,
-            "realtime_factor": L * n_it / dtm / ch.fs, "includes": "PCIe H2D of every block"}
+            "realtime_factor": L * n_it / dtm / ch.fs, "includes": "PCIe H2D of every block (sdrxgpu_bank_process_pinned)"}
         for bk in banks:
             bk.close()
 
@@ -272,28 +399,31 @@ def main():
     if world == 1 and not args.no_extra_configs:
         # the drop-in entry (host pointers in and out, outputs complete on return): PCIe-inclusive, NOT `value`
         tabs = sb.translators_for(ch, offs)
-        hb = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank)
+        hb = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, tuning=tuning)
         x_host = synth.synth_iq(9, 0, L, 0.25)
         o_iq = np.zeros((n_ch, 512), dtype=np.complex64)
         o_au = np.zeros((n_ch, 512), dtype=np.float32)
         res = {}
-        for label, pin in (("pageable", False), ("page_locked", True)):
+        for label, pin, kw in (("pageable", False, {}), ("page_locked", True, {}), ("page_locked_audio_only", True, {"iq": False})):
             if pin:
                 for a_ in (x_host, o_iq, o_au):
                     sb.host_register(a_)
+            io = dict(iq_out=o_iq if kw.get("iq", True) else None, audio_out=o_au)
             for _ in range(2):
-                hb.process(x_host, iq_out=o_iq, audio_out=o_au)
+                hb.process(x_host, **io)
             n_it = 8
             t0 = time.perf_counter()
             for _ in range(n_it):
-                hb.process(x_host, iq_out=o_iq, audio_out=o_au)
+                hb.process(x_host, **io)
             dth = (time.perf_counter() - t0) / n_it
             res[label] = {"ms_per_block": dth * 1e3, "value": n_ch * L / dth / 1e6}
             if pin:
                 for a_ in (x_host, o_iq, o_au):
                     sb.host_unregister(a_)
         hb.close()
-        host_path = {"what": f"sdrxgpu_bank_process: {L * 8 / 1e6:.2f} MB H2D + {n_ch * 512 * 12 / 1e6:.1f} MB D2H per block, synchronous",
+        host_path = {"what": f"sdrxgpu_bank_process: {L * 8 / 1e6:.2f} MB H2D + {n_ch * 512 * 12 / 1e6:.1f} MB D2H per block "
+                             f"({n_ch * 512 * 4 / 1e6:.1f} MB audio-only), outputs complete on return; the bank runs as two channel "
+                             f"halves so that the D2H of the first overlaps the kernels of the second",
                      "unit": "Mch-samples/s", **res}
 
     if rank == 0:
@@ -301,8 +431,27 @@ def main():
         value = total_cs / dt / 1e6
         bpu = algorithmic_bytes_per_channel_sample(ch.m_total)
         k12_ms, k12_n = k["k_stage12"]
-        achieved = bpu * n_ch * L / (k12_ms / 1e3) / 1e9 if k12_n else None
-        traffic, traffic_src = measured_traffic(n_ch)
+        units = float(n_ch) * L                                   # channel-samples per launch
+        f12 = flops_per_channel_sample(ch, 3 if fused else 2)     # what k_stage12 computes per channel-sample
+        f_all = flops_per_channel_sample(ch, len(ch.stages))
+        ach_tf = f12 * units / (k12_ms / 1e3) / 1e12 if k12_n else None
+        prof, prof_src = profile_facts(n_ch, fused)
+        n_y2, n_y3 = L // (ch.stages[0].m * ch.stages[1].m), L // (ch.stages[0].m * ch.stages[1].m * ch.stages[2].m)
+        if fused:     # k_tail4: [hist3 | y3] + the range-boundary buffer in, decimated IQ out twice (caller's buffer + the AGC's)
+            tail_bytes = n_ch * (8.0 * (n_y3 + 80) + 8.0 * 40 * ((n_y2 + 767) // 768) + 2 * 8.0 * 512)
+        else:         # k_tail_s: the stage-2 scratch in, decimated IQ out twice
+            tail_bytes = n_ch * (8.0 * n_y2 + 2 * 8.0 * 512)
+        kern = {
+            "k_stage12": {"ms": k12_ms, "bound": "valu_fp32", "flops_per_unit": f12, "achieved_tflops": ach_tf,
+                          "frac": ach_tf / FP32_PEAK_TF if ach_tf else None,
+                          "does": "mixer + stages 1-2" + (" + stage 3 of the workgroup's own range (fused)" if fused else "")},
+            "k_tail": {"ms": k["k_tail"][0], "bound": "hbm", "algorithmic_bytes": tail_bytes,
+                       "achieved_gbs": tail_bytes / (k["k_tail"][0] / 1e3) / 1e9 if k["k_tail"][1] else None,
+                       "frac": tail_bytes / (k["k_tail"][0] / 1e3) / 1e9 / HBM_PEAK_GBS if k["k_tail"][1] else None,
+                       "does": "k_tail4: range-boundary stage-3 outputs + stage 4" if fused else "k_tail_s: stages 3-4 from the stage-2 scratch"},
+            "k_agc": {"ms": k["k_agc"][0], "bound": "latency (512 dependent steps per channel)",
+                      "ns_per_step": k["k_agc"][0] * 1e6 / 512 if k["k_agc"][1] else None},
+        }
         out = {
             "metric": "IQ Msamples/s ingested x channels demodulated (channel-samples/s)",
             "value": value, "unit": "Mch-samples/s",
@@ -316,24 +465,39 @@ def main():
                             f"mixer + 4-stage FIR decimation /{ch.m_total} + IF-AGC + AM envelope",
                 "channels_per_gpu": n_ch, "channels_total": n_ch * world, "sample_rate": ch.fs, "block_len": L,
                 "outputs_per_channel_per_block": 512,
-                "parallelism": f"channel-sharded x{world}" + (", RCCL broadcast of the IQ block per step" if world > 1 else ""),
+                "parallelism": f"channel-sharded over {world} RCCL rank(s)" +
+                               (", block k+1 broadcast over xGMI into the banks' other input ring while block k is processed"
+                                if (world > 1 or args.force_dist) else ""),
+                "kernel_path": "stage 3 fused behind stages 1-2 (k_stage12 + k_tail4 + k_agc)" if fused else
+                               "separate tail (k_stage12 + k_tail_s + k_agc)",
                 "realtime_factor": value * 1e6 / (n_ch * world * ch.fs),
                 "settle_steps": SETTLE_STEPS,    # untimed, before the W warm-up steps (clock settling, see time_bank)
                 "call_semantics": "drop-in: call k returns block k" if not args.pipelined else
                                   "pipelined: call k returns block k-1 (bit-identical outputs, one block of latency)",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_stage12 (mixer + stages 1-2)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": bpu * n_ch * L,
-                "kernel_ms_avg": {n: v[0] for n, v in k.items()},
-                "kernel_ms_note": "k_stage12: HIP events inside the timed region; k_tail / k_agc: from 5 extra steps run right after it",
+                # the ceiling that binds: fp32 vector issue.  achieved = the flop the reference's
+                # algorithm does per channel-sample in this kernel x channel-samples per launch / the kernel's mean
+                # duration (HIP events on the bank's stream, inside the timed region)
+                "bound": "valu_fp32", "kernel": "k_stage12",
+                "achieved": ach_tf, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": ach_tf / FP32_PEAK_TF if ach_tf else None,
+                "flops_per_unit": f12, "flops_per_unit_whole_step": f_all,
+                "whole_step_tflops": f_all * units / (dt / args.steps) / 1e12,
+                "traffic": prof.get("k_stage12_hbm_bytes_per_launch") if prof else None,
+                "traffic_source": prof_src,
+                "sustained_clock_ghz": prof.get("sustained_clock_ghz") if prof else None,
                 "launches": int(k12_n),
-                "note": "achieved = ALGORITHMIC bytes (8.02 B per channel-sample) / kernel time; the IQ block is shared by "
-                        "all channels on chip, so physical HBM traffic is far smaller and the kernel is bound by packed-fp32 "
-                        "VALU issue, not by HBM (DESIGN.md)",
+                "kernels": kern,
+                "kernel_ms_note": "k_stage12: HIP events inside the timed region; k_tail / k_agc: from 5 extra steps run right after it",
+                # north_star's figure, kept under its own name: ALGORITHMIC bytes (every channel-sample counted
+                # as 8.02 B although the IQ block is shared by all channels on chip) over the kernel time.  It exceeds the
+                # HBM peak by construction and is not a fraction of any ceiling.
+                "algorithmic_hbm": {"bytes_per_unit": bpu, "bytes_per_launch": bpu * units,
+                                    "gbs_over_k_stage12": bpu * units / (k12_ms / 1e3) / 1e9 if k12_n else None,
+                                    "gbs_over_step": bpu * units / (dt / args.steps) / 1e9,
+                                    "hbm_peak_gbs": HBM_PEAK_GBS,
+                                    "ratio_to_hbm_peak_over_step": bpu * units / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             },
         }
         if extra:

@@ -200,11 +200,27 @@ int sdrxgpu_bank_process_device(sdrxgpu_bank *bank, const void *d_iq_in, size_t 
                                 void *d_iq_out, void *d_audio_out, size_t out_stride,
                                 size_t *out_len);
 
+/* The throughput entry between the two: iq_in is PAGE-LOCKED host memory (hipHostMalloc / sdrxgpu_host_register),
+ * the outputs are device pointers, and nothing waits: the H2D copy is queued on the bank's copy stream into the
+ * input ring the previous block's kernels are not reading (so it runs beside them), this block's kernels follow on
+ * the bank's stream.  iq_in must stay unchanged until the NEXT call on this bank has begun (it waits for the copy
+ * if it has not finished -- the device layer's double buffer gives exactly that, airspy_dev.cpp:410-414) or
+ * sdrxgpu_bank_synchronize has returned.  Several banks (config 5: 16 streams) driven this way from one or more
+ * threads overlap each other's copies and kernels. */
+int sdrxgpu_bank_process_pinned(sdrxgpu_bank *bank, const sdrxgpu_iq *iq_in, size_t in_len,
+                                void *d_iq_out, void *d_audio_out, size_t out_stride, size_t *out_len);
+
 /* Pipelined banks: outputs of the block whose tail is still pending (device pointers, bank's stream). */
 int sdrxgpu_bank_flush(sdrxgpu_bank *bank, void *d_iq_out, void *d_audio_out, size_t out_stride, size_t *out_len);
 
-/* Device address where the NEXT block may be written directly, and its capacity in samples. */
+/* Device address where the NEXT block may be written directly, and its capacity in samples.  The bank has two
+ * input rings and uses them alternately (each call of at most max_in_len samples flips), so that block k+1 can
+ * arrive -- H2D copy, RCCL broadcast -- while the kernels of block k still read the other ring. */
 int sdrxgpu_bank_ingest_buffer(sdrxgpu_bank *bank, void **d_ptr, size_t *capacity);
+/* The same for the block AFTER a next call of in_len samples (in_len <= max_in_len): where block k+1 may be
+ * written before, or while, block k is processed.  Passing these addresses to sdrxgpu_bank_process_device makes
+ * the call copy-free; any other address is copied in, as before. */
+int sdrxgpu_bank_ingest_buffer_after(sdrxgpu_bank *bank, size_t in_len, void **d_ptr);
 
 /* Page-lock caller memory that is handed to sdrxgpu_bank_process again and again (the IQ double buffer of the
  * device layer, the chunks of the CRB ring, reference src/crb.hpp:56): H2D/D2H then go by DMA straight from/to

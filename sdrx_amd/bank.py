@@ -121,11 +121,13 @@ def load_library():
     L.sdrxgpu_bank_reset.argtypes = [vp]
     L.sdrxgpu_bank_process.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(sz)]
     L.sdrxgpu_bank_process_device.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(sz)]
+    L.sdrxgpu_bank_process_pinned.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(sz)]
     L.sdrxgpu_bank_flush.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
     L.sdrxgpu_bank_ingest_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.sdrxgpu_host_register.argtypes = [vp, sz]
     L.sdrxgpu_host_unregister.argtypes = [vp]
     L.sdrxgpu_bank_synchronize.argtypes = [vp]
+    L.sdrxgpu_bank_ingest_buffer_after.argtypes = [vp, sz, C.POINTER(vp)]
     L.sdrxgpu_bank_get_info.argtypes = [vp, C.POINTER(BankInfo)]
     L.sdrxgpu_bank_get_gains.argtypes = [vp, vp, vp]
     L.sdrxgpu_bank_get_squelch.argtypes = [vp, vp, vp]
@@ -141,7 +143,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "sdrxgpu_agc_params_sdrx", "sdrxgpu_make_translator", "sdrxgpu_bank_create", "sdrxgpu_bank_destroy",
-    "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_flush", "sdrxgpu_bank_ingest_buffer",
+    "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_process_pinned", "sdrxgpu_bank_flush", "sdrxgpu_bank_ingest_buffer", "sdrxgpu_bank_ingest_buffer_after",
     "sdrxgpu_host_register", "sdrxgpu_host_unregister", "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_get_squelch", "sdrxgpu_bank_profile_enable",
     "sdrxgpu_audio_pos", "sdrxgpu_bank_get_mix", "sdrxgpu_bank_mix_buffers",
     "sdrxgpu_bank_profile_read", "sdrxgpu_bank_profile_reset", "sdrxgpu_strerror", "sdrxgpu_last_error",
@@ -361,6 +363,14 @@ class ChannelBank:
                                                    out_stride, C.byref(n_out)), "sdrxgpu_bank_process_device")
         return n_out.value
 
+    def process_pinned(self, host_in_ptr, in_len, d_iq_out_ptr, d_audio_out_ptr, out_stride):
+        """Page-locked host block in, device pointers out, nothing waits (H2D on the bank's copy stream into its
+        free input ring).  The host block must stay unchanged until the next call on this bank or ``synchronize``."""
+        n_out = C.c_size_t(0)
+        _check(self._L.sdrxgpu_bank_process_pinned(self._h, host_in_ptr, in_len, d_iq_out_ptr, d_audio_out_ptr,
+                                                   out_stride, C.byref(n_out)), "sdrxgpu_bank_process_pinned")
+        return n_out.value
+
     def flush(self, d_iq_out_ptr, d_audio_out_ptr, out_stride):
         """Pipelined banks: outputs of the block whose tail stages are still pending."""
         n_out = C.c_size_t(0)
@@ -371,6 +381,12 @@ class ChannelBank:
         p, cap = C.c_void_p(), C.c_size_t()
         _check(self._L.sdrxgpu_bank_ingest_buffer(self._h, C.byref(p), C.byref(cap)), "sdrxgpu_bank_ingest_buffer")
         return p.value, cap.value
+
+    def ingest_buffer_after(self, in_len):
+        """Where the block after a next call of ``in_len`` samples may be written (the bank's other input ring)."""
+        p = C.c_void_p()
+        _check(self._L.sdrxgpu_bank_ingest_buffer_after(self._h, in_len, C.byref(p)), "sdrxgpu_bank_ingest_buffer_after")
+        return p.value
 
     # ---- timing (HIP events on the bank's stream) ----
     def profile_enable(self, on=True):

@@ -250,8 +250,9 @@ struct Stage12Args {
     int nb;                 // bodies per lane (divides spacing/SB)
     int P;                  // (spacing/SB)/nb sub-phases per segment
     int n_wt;               // time-waves = G*P
-    int n_chgroups;
-    int n_cgx;              // n_chgroups rounded up to a multiple of 8 (XCD-aware block map)
+    int cg0;                // first channel group of this launch (a launch may cover part of the bank)
+    int n_chgroups;         // one past its last channel group
+    int n_cgx;              // channel groups of the launch rounded up to a multiple of 8 (XCD-aware block map)
     // fused stage 3 (k_stage12<.., MA, TA> with MA > 0; P == 1): stage-3 output rr of this call (0-based) has the call's
     // stage-2 outputs MA*rr + c0 - (TA-1) .. MA*rr + c0 as its window
     int y3_stride;
@@ -339,7 +340,7 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
     const int xcd = blockIdx.x & 7;
     const int qq = blockIdx.x >> 3;
     const int wt = qq % a.n_wt;
-    const int cg = (qq / a.n_wt) * 8 + xcd;
+    const int cg = a.cg0 + (qq / a.n_wt) * 8 + xcd;
     if (cg >= a.n_chgroups) return;
     const int g = wt / a.P;
     const int p = wt - g * a.P;
@@ -608,7 +609,8 @@ struct TailArgs {
     float2       *hist_out; // [n_ch][hist]
     float2       *iq_out;   // [n_ch][out_stride] or nullptr
     float2       *iq_keep;  // [n_ch][keep_stride] compact copy for k_agc (never null)
-    int n_ch;
+    int n_ch;               // one past the last channel of this launch
+    int ch_lo;              // its first channel (a launch may cover part of the bank)
     int y2_stride, hist, n_y2_new;
     int out_stride, keep_stride;
     int has_a;              // 1: stage A then stage B; 0: stage B only
@@ -666,6 +668,7 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
     // channels are walked from the last to the first: the stage-1/2 kernel wrote the high channel
     // groups last, so their rows are the ones still held by the Infinity Cache / L2
     const int ch = a.n_ch - 1 - chf;
+    if (ch < a.ch_lo) return;
     const int tid = threadIdx.x;
     const float2 *__restrict__ ynew = a.y2_new + (size_t)ch * a.y2_stride;
     const float2 *__restrict__ hin = a.hist_in + (size_t)ch * a.hist;
@@ -794,6 +797,7 @@ __global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
     const int chf = (qq / a.n_tiles) * 8 + xcd;
     if (chf >= a.n_ch) return;
     const int ch = a.n_ch - 1 - chf;
+    if (ch < a.ch_lo) return;
     const int tid = threadIdx.x;
     const float2 *__restrict__ ynew = a.y2_new + (size_t)ch * a.y2_stride;
     const float2 *__restrict__ hin = a.hist_in + (size_t)ch * a.hist;
@@ -1005,7 +1009,8 @@ struct AgcArgs {
     const float2 *iq;        // [n_ch][iq_stride] decimated IQ; rows 16-byte aligned
     float        *audio;     // [n_ch][out_stride]
     float4       *state;     // [n_ch] {agc.gain, agc.power, lf.gain, lf.power}
-    int n_ch, n_out, iq_stride, out_stride;
+    int n_ch, n_out, iq_stride, out_stride;   // n_ch: one past the last channel of this launch
+    int ch_lo;               // its first channel
     int lf_active;
     int audio_vec;           // 1: audio rows are 16-byte aligned (vector stores)
     AgcParams agc, lf;
@@ -1115,7 +1120,7 @@ __global__ __launch_bounds__(4 * kWave) void k_agc(const AgcArgs a)
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & (kWave - 1);
-    const int ch0 = blockIdx.x * kWave;                      // first channel of this workgroup
+    const int ch0 = a.ch_lo + blockIdx.x * kWave;            // first channel of this workgroup
     const int chr = ch0 + lane;
     const bool ok = chr < a.n_ch;                            // (lanes past the last channel work on the last row and store nothing)
     const int ch = ok ? chr : a.n_ch - 1;

@@ -257,11 +257,22 @@ struct sdrxgpu_bank {
         bool valid = false;
         TailArgs t;
         int c0 = 0, n_y3 = 0, d0 = 0, n_bnd = 0;   // fused banks (Tail4Args)
+        K12Launch L;                                // the stage-1/2 launch of this chunk (launch_k12_range)
         const float2 *roll_from = nullptr;   // input-history copy left for k_agc to do (serial mode)
         float2 *roll_to = nullptr;
         int roll_cnt = 0;
     } pending;
     int y2_cur = 0;
+
+    // host entries: copies on their own stream beside the kernels (sdrxgpu_bank_process: D2H of the first channel half
+    // beside the kernels of the second; sdrxgpu_bank_process_pinned: H2D of block k+1 beside the kernels of block k)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_part[2] = {nullptr, nullptr};       // kernels of a channel half are done
+    hipEvent_t ev_h2d = nullptr;                      // the block is in the input ring
+    hipEvent_t ev_d2h = nullptr;                      // the output rows have left the keep buffers
+    hipEvent_t ev_ring_free[2] = {nullptr, nullptr};  // the kernels that read input ring r are done
+    bool ring_busy[2] = {false, false};
+    bool h2d_pending = false;
 
     // stream position
     uint64_t n_in = 0, n_out = 0;
@@ -304,6 +315,12 @@ static void free_bank(sdrxgpu_bank *b)
         (void)hipStreamSynchronize(b->stream2);
         (void)hipStreamDestroy(b->stream2);
     }
+    if (b->copy_stream) {
+        (void)hipStreamSynchronize(b->copy_stream);
+        (void)hipStreamDestroy(b->copy_stream);
+    }
+    for (hipEvent_t e : {b->ev_part[0], b->ev_part[1], b->ev_h2d, b->ev_d2h, b->ev_ring_free[0], b->ev_ring_free[1]})
+        if (e) (void)hipEventDestroy(e);
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     (void)hipFree(b->d_hist[0]);
@@ -338,6 +355,9 @@ static void free_bank(sdrxgpu_bank *b)
 static int init_state(sdrxgpu_bank *b)
 {
     if (b->stream2) HIPCHK(hipStreamSynchronize(b->stream2));
+    if (b->copy_stream) HIPCHK(hipStreamSynchronize(b->copy_stream));
+    b->ring_busy[0] = b->ring_busy[1] = false;
+    b->h2d_pending = false;
     b->pending.valid = false;
     b->y2_cur = 0;
     HIPCHK(hipMemsetAsync(b->d_xr[0], 0, b->x_capacity * sizeof(float2), b->stream));
@@ -829,6 +849,8 @@ extern "C" int sdrxgpu_bank_synchronize(sdrxgpu_bank *b)
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_synchronize: null bank");
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->stream2) HIPCHK(hipStreamSynchronize(b->stream2));
+    if (b->copy_stream) HIPCHK(hipStreamSynchronize(b->copy_stream));
+    b->h2d_pending = false;
     return SDRXGPU_OK;
 }
 
@@ -852,6 +874,26 @@ extern "C" int sdrxgpu_bank_ingest_buffer(sdrxgpu_bank *b, void **d_ptr, size_t 
     if (!b || !d_ptr) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_ingest_buffer: null argument");
     *d_ptr = b->d_xr[b->xr] + ((long long)b->n_in - b->x_origin);
     if (capacity) *capacity = b->max_chunk;
+    return SDRXGPU_OK;
+}
+
+// where the history of a chunk ending at absolute sample n1 starts: HIST samples back, one more when the next call's
+// first body would otherwise start on an odd index of the ring (16-byte LDS-DMA sources)
+static long long origin_after(const sdrxgpu_bank *b, long long n1)
+{
+    const long long s0_next = (n1 / b->MM) * b->MM;
+    long long origin_next = n1 - b->HIST;
+    if ((origin_next - s0_next) & 1) origin_next -= 1;
+    return origin_next;
+}
+
+extern "C" int sdrxgpu_bank_ingest_buffer_after(sdrxgpu_bank *b, size_t in_len, void **d_ptr)
+{
+    if (!b || !d_ptr) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_ingest_buffer_after: null argument");
+    if (in_len == 0 || in_len > b->max_chunk)
+        return fail(SDRXGPU_ERR_INVALID_ARG, "bank_ingest_buffer_after: in_len %zu (1 .. max_in_len = %u)", in_len, b->max_chunk);
+    const long long n1 = (long long)b->n_in + (long long)in_len;
+    *d_ptr = b->d_xr[b->xr ^ 1] + (n1 - origin_after(b, n1));
     return SDRXGPU_OK;
 }
 
@@ -962,7 +1004,21 @@ static size_t outputs_of(const sdrxgpu_bank *b, uint64_t n0, size_t len)
 
 // Stage-1/2 of one chunk (<= max_chunk samples, already in the input ring) on stream `st`; fills `job` with
 // everything the tail launch needs except the output pointers and the history ping-pong side.
-static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2 *y2buf, sdrxgpu_bank::TailJob *job)
+// Launch the stage-1/2 kernel of a prepared chunk for the channel groups [cg_lo, cg_hi).
+static int launch_k12_range(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStream_t st, int cg_lo, int cg_hi)
+{
+    K12Launch L = job->L;
+    L.args.cg0 = cg_lo;
+    L.args.n_chgroups = cg_hi;
+    L.args.n_cgx = (cg_hi - cg_lo + 7) / 8 * 8;
+    L.grid = L.args.n_cgx * L.args.n_wt;
+    ProfScope ps(b, SDRXGPU_K_STAGE12, st);
+    HIPCHK((b->fused ? b->k12->fn_fused : b->k12->fn)(L, st));
+    return SDRXGPU_OK;
+}
+
+// `defer`: prepare only (the caller launches the stage-1/2 kernel itself, by channel ranges: launch_k12_range)
+static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2 *y2buf, sdrxgpu_bank::TailJob *job, bool defer = false)
 {
     const K12Entry *k = b->k12;
     const long long n0 = (long long)b->n_in, n1 = n0 + (long long)in_len;
@@ -999,6 +1055,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         const int SPW = kWave / b->CPW;
         const long long G = (U + (long long)SPW * b->bps - 1) / ((long long)SPW * b->bps);
         a.n_wt = (int)(G * b->P);
+        a.cg0 = 0;
         a.n_chgroups = (int)((b->n_ch + b->W * b->CPW - 1) / (b->W * b->CPW));
         a.n_cgx = (a.n_chgroups + 7) / 8 * 8;
         if (a.x_base < 0 || (a.x_base & 1) || (a.tphase0 & 1))
@@ -1037,9 +1094,10 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
             if (job->n_y3 > b->y3_stride - 2 || job->n_bnd > 64)
                 return fail(SDRXGPU_ERR_HIP, "internal: %d stage-3 outputs / %d range boundaries exceed the fused path's buffers", job->n_y3, job->n_bnd);
         }
-        {
-            ProfScope ps(b, SDRXGPU_K_STAGE12, st);
-            HIPCHK((b->fused ? k->fn_fused : k->fn)(L, st));
+        job->L = L;
+        if (!defer) {
+            const int rc = launch_k12_range(b, job, st, 0, a.n_chgroups);
+            if (rc) return rc;
         }
 
         // ---- parameters of the remaining stage(s) ----
@@ -1096,9 +1154,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
     // keep the last HIST (+1 when the next call's first body would otherwise start on an odd index)
     // input samples in front of the next block
     {
-        const long long s0_next = (n1 / b->MM) * b->MM;
-        long long origin_next = n1 - b->HIST;
-        if ((origin_next - s0_next) & 1) origin_next -= 1;
+        const long long origin_next = origin_after(b, n1);
         const int src_off = (int)(origin_next - b->x_origin);
         const int cnt = (int)(n1 - origin_next);
         if (src_off < 0) return fail(SDRXGPU_ERR_HIP, "internal: history roll offset %d < 0", src_off);
@@ -1124,11 +1180,15 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
 }
 
 // Tail stage(s) + AGC/demod of a prepared job on the bank's stream, outputs to the given device pointers.
+// [ch_lo, ch_hi): the channels of this launch (ch_hi < 0: the whole bank); `last`: the last (or only) part of the chunk --
+// what concerns the whole bank (history copy, squelch / audio FIR / mix-down, the output count) happens with it.
 static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq_out, float *d_audio_out, size_t out_stride,
-                       size_t out_off, size_t *produced)
+                       size_t out_off, size_t *produced, int ch_lo = 0, int ch_hi = -1, bool last = true)
 {
     *produced = 0;
     if (!job->valid) return SDRXGPU_OK;
+    if (ch_hi < 0) ch_hi = (int)b->n_ch;
+    const unsigned n_part = (unsigned)(ch_hi - ch_lo);
     TailArgs &t = job->t;
     // (process_impl / bank_flush have validated out_stride and the squelch's 512-output rule before anything was
     // launched; these two are internal consistency checks and leave the job untouched)
@@ -1136,7 +1196,9 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "internal: %zu outputs per channel but out_stride is %zu", out_off + t.n_b, out_stride);
     if (b->squelch && t.n_b != 512)
         return fail(SDRXGPU_ERR_UNSUPPORTED, "internal: squelch chunk of %d outputs", t.n_b);
-    job->valid = false;
+    if (last) job->valid = false;
+    t.n_ch = ch_hi;
+    t.ch_lo = ch_lo;
     t.iq_out = d_iq_out ? d_iq_out + out_off : nullptr;
     t.out_stride = (int)out_stride;
     if (b->fused) {
@@ -1160,9 +1222,9 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         const size_t lds = ((size_t)b->H3 + job->n_y3 + 2) * sizeof(float2);
         const K12Entry *k = b->k12;
         if (k->MA == 5 && k->TA == 21 && k->MB == 5 && k->TB == 67)
-            hipLaunchKernelGGL((k_tail4<5, 21, 5, 67>), dim3(b->n_ch), dim3(256), lds, b->stream, f);
+            hipLaunchKernelGGL((k_tail4<5, 21, 5, 67>), dim3(n_part), dim3(256), lds, b->stream, f);
         else if (k->MA == 5 && k->TA == 19 && k->MB == 5 && k->TB == 45)
-            hipLaunchKernelGGL((k_tail4<5, 19, 5, 45>), dim3(b->n_ch), dim3(256), lds, b->stream, f);
+            hipLaunchKernelGGL((k_tail4<5, 19, 5, 45>), dim3(n_part), dim3(256), lds, b->stream, f);
         else
             return fail(SDRXGPU_ERR_HIP, "internal: no k_tail4 for this chain");
         HIPCHK(hipGetLastError());
@@ -1170,7 +1232,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         t.hist_in = b->d_hist[b->hist_cur];
         t.hist_out = b->d_hist[b->hist_cur ^ 1];
         ProfScope ps(b, SDRXGPU_K_TAIL);
-        const dim3 grid(((b->n_ch + 7) / 8 * 8) * t.n_tiles);
+        const dim3 grid(((n_part + 7) / 8 * 8) * t.n_tiles);
         const int mA = t.has_a ? t.mA : 0, tA = t.has_a ? t.tA : 0;
         // the tail stages of the reference's chains (sdrx.cpp:1588-1668) are compiled in; anything else runs generic
 #define SDRX_TAIL_CASE(MA_, TA_, MB_, TB_)                                                                       \
@@ -1185,7 +1247,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             hipLaunchKernelGGL(k_tail, grid, dim3(256), b->tail_lds, b->stream, t);
 #undef SDRX_TAIL_CASE
         HIPCHK(hipGetLastError());
-        b->hist_cur ^= 1;
+        if (last) b->hist_cur ^= 1;
     }
 
     // ---- AGC -> |.| -> LF AGC ----
@@ -1196,7 +1258,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         g.audio = d_audio_out ? d_audio_out + out_off : b->d_audio_keep;
         g.out_stride = d_audio_out ? (int)out_stride : b->keep_stride;
         g.state = b->d_state;
-        g.n_ch = (int)b->n_ch;
+        g.n_ch = ch_hi;
+        g.ch_lo = ch_lo;
         g.n_out = t.n_b;
         g.lf_active = (b->flags & SDRXGPU_FLAG_LF_AGC_ACTIVE) ? 1 : 0;
         g.audio_vec = (((uintptr_t)g.audio & 15) == 0 && (g.out_stride & 3) == 0) ? 1 : 0;
@@ -1214,9 +1277,9 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         g.fm_prev = b->d_fm_prev;
         g.roll_from = job->roll_from;
         g.roll_to = job->roll_to;
-        g.roll_cnt = job->roll_cnt;
-        job->roll_cnt = 0;
-        const unsigned agc_blocks = (unsigned)((b->n_ch + kWave - 1) / kWave) + (g.roll_cnt > 0 ? 1u : 0u);
+        g.roll_cnt = last ? job->roll_cnt : 0;
+        if (last) job->roll_cnt = 0;
+        const unsigned agc_blocks = (n_part + kWave - 1) / kWave + (g.roll_cnt > 0 ? 1u : 0u);
         g.sql = b->squelch ? b->d_sql : nullptr;
         g.ramp_up = b->squelch ? b->d_sq_tabs + 1024 : nullptr;      // 16-byte aligned (offsets are multiples of 512 floats)
         g.ramp_down = b->squelch ? b->d_sq_tabs + 1536 : nullptr;
@@ -1231,6 +1294,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         else
             hipLaunchKernelGGL((k_agc<false, false>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<false>), b->stream, g);
         HIPCHK(hipGetLastError());
+        // (banks with squelch, audio FIR or mix-down are never run in parts: these work on the whole bank)
         if (b->squelch) {
             SquelchArgs q;
             q.iq = b->d_keep;
@@ -1290,8 +1354,10 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             b->mix_frames = t.n_b;
         }
     }
-    *produced = (size_t)t.n_b;
-    b->n_out += (uint64_t)t.n_b;
+    if (last) {
+        *produced = (size_t)t.n_b;
+        b->n_out += (uint64_t)t.n_b;
+    }
     return SDRXGPU_OK;
 }
 
@@ -1328,6 +1394,89 @@ static int run_chunk_pipelined(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out,
     return SDRXGPU_OK;
 }
 
+// Everything that can refuse a call is checked HERE, before any launch or state change: a refused call leaves the
+// bank exactly as it was (MSD::decimate cannot fail, msd.hpp:75; the next call must still be right).
+static int validate_call(const sdrxgpu_bank *b, size_t in_len, bool has_outs, size_t out_stride)
+{
+    uint64_t pos = b->n_in;
+    size_t left = in_len, total_out = 0;
+    while (left) {
+        const size_t n = std::min(left, (size_t)b->max_chunk);
+        const size_t k = outputs_of(b, pos, n);
+        if (b->squelch && (pos + n) / b->MM > pos / b->MM && k != 512)
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a bank with squelch takes whole 512-output chunks (this call produces %zu)", k);
+        total_out += k;
+        pos += n;
+        left -= n;
+    }
+    const size_t returned = b->pipelined ? (b->pending.valid ? (size_t)b->pending.t.n_b : 0) : total_out;
+    if (has_outs && returned > out_stride)
+        return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", returned, out_stride);
+    return SDRXGPU_OK;
+}
+
+static int ensure_copy_stream(sdrxgpu_bank *b)
+{
+    if (b->copy_stream) return SDRXGPU_OK;
+    HIPCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&b->ev_part[0], &b->ev_part[1], &b->ev_h2d, &b->ev_d2h, &b->ev_ring_free[0], &b->ev_ring_free[1]})
+        HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return SDRXGPU_OK;
+}
+
+static int gcd_int(int a, int c) { return c ? gcd_int(c, a % c) : a; }
+
+// One chunk with HOST outputs.  The kernels write the compact keep buffers and the rows are copied out from there.  A
+// large plain bank runs as two channel halves: the rows of the first half cross PCIe on the copy stream while the
+// kernels of the second half run (61 MB of D2H per 10 000-channel block take as long as its kernels).
+static int run_chunk_host(sdrxgpu_bank *b, size_t in_len, void *iq_out, void *audio_out, size_t out_stride, size_t out_off,
+                          size_t *produced)
+{
+    *produced = 0;
+    sdrxgpu_bank::TailJob job;
+    int rc = launch_stage12(b, in_len, b->stream, b->d_y2, &job, /*defer=*/true);
+    if (rc || !job.valid) return rc;
+    const int n_b = job.t.n_b;
+    const int gsz = b->W * b->CPW;
+    const int unit = gsz / gcd_int(gsz, kWave) * kWave;                 // whole channel groups and whole k_agc blocks
+    const bool copies = n_b > 0 && (iq_out || audio_out);
+    int mid = (int)b->n_ch;
+    if (copies && !b->squelch && !b->fir_T && !b->mix && b->n_ch >= 2048) {
+        mid = (((int)b->n_ch / 2 + unit - 1) / unit) * unit;
+        if (mid >= (int)b->n_ch) mid = (int)b->n_ch;
+    }
+    const int n_parts = mid < (int)b->n_ch ? 2 : 1;
+    if (n_parts > 1 && (rc = ensure_copy_stream(b))) return rc;
+    for (int p = 0; p < n_parts; p++) {
+        const int ch_lo = p ? mid : 0, ch_hi = (p == n_parts - 1) ? (int)b->n_ch : mid;
+        if ((rc = launch_k12_range(b, &job, b->stream, ch_lo / gsz, (ch_hi + gsz - 1) / gsz))) return rc;
+        size_t prod = 0;
+        if ((rc = launch_tail(b, &job, nullptr, nullptr, b->keep_stride, 0, &prod, ch_lo, ch_hi, p == n_parts - 1))) return rc;
+        if (!copies) continue;
+        hipStream_t cs = b->stream;
+        if (n_parts > 1) {
+            HIPCHK(hipEventRecord(b->ev_part[p], b->stream));
+            HIPCHK(hipStreamWaitEvent(b->copy_stream, b->ev_part[p], 0));
+            cs = b->copy_stream;
+        }
+        const size_t rows = (size_t)(ch_hi - ch_lo);
+        if (iq_out)
+            HIPCHK(hipMemcpy2DAsync((float2 *)iq_out + (size_t)ch_lo * out_stride + out_off, out_stride * sizeof(float2),
+                                    b->d_keep + (size_t)ch_lo * b->keep_stride, (size_t)b->keep_stride * sizeof(float2),
+                                    (size_t)n_b * sizeof(float2), rows, hipMemcpyDeviceToHost, cs));
+        if (audio_out)
+            HIPCHK(hipMemcpy2DAsync((float *)audio_out + (size_t)ch_lo * out_stride + out_off, out_stride * sizeof(float),
+                                    b->d_audio_keep + (size_t)ch_lo * b->keep_stride, (size_t)b->keep_stride * sizeof(float),
+                                    (size_t)n_b * sizeof(float), rows, hipMemcpyDeviceToHost, cs));
+    }
+    if (n_parts > 1) {      // the keep buffers are free again (next chunk, next call) once the copies have read them
+        HIPCHK(hipEventRecord(b->ev_d2h, b->copy_stream));
+        HIPCHK(hipStreamWaitEvent(b->stream, b->ev_d2h, 0));
+    }
+    *produced = (size_t)n_b;
+    return SDRXGPU_OK;
+}
+
 static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t in_len, void *iq_out, void *audio_out,
                         bool out_is_host, size_t out_stride, size_t *out_len)
 {
@@ -1338,26 +1487,13 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
         return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a pipelined bank takes device pointers and at most max_in_len samples per call");
     if (b->mix && in_len > b->max_chunk)
         return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a bank with mix-down takes at most max_in_len = %u samples per call", b->max_chunk);
-    // Everything that can refuse the call is checked HERE, before any launch or state change: a refused call
-    // leaves the bank exactly as it was (MSD::decimate cannot fail, msd.hpp:75; the next call must still be right).
     {
-        uint64_t pos = b->n_in;
-        size_t left = in_len, total_out = 0;
-        while (left) {
-            const size_t n = std::min(left, (size_t)b->max_chunk);
-            const size_t k = outputs_of(b, pos, n);
-            if (b->squelch && (pos + n) / b->MM > pos / b->MM && k != 512)
-                return fail(SDRXGPU_ERR_UNSUPPORTED, "process: a bank with squelch takes whole 512-output chunks (this call produces %zu)", k);
-            total_out += k;
-            pos += n;
-            left -= n;
-        }
-        const size_t returned = b->pipelined ? (b->pending.valid ? (size_t)b->pending.t.n_b : 0) : total_out;
-        if ((iq_out || audio_out) && returned > out_stride)
-            return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "process: %zu outputs per channel but out_stride is %zu", returned, out_stride);
+        const int rc = validate_call(b, in_len, iq_out || audio_out, out_stride);
+        if (rc) return rc;
     }
     HIPCHK(hipSetDevice(b->device));
     if (b->mix && !b->pipelined) b->mix_frames = 0;
+    b->ring_busy[0] = b->ring_busy[1] = false;      // (sdrxgpu_bank_process_pinned's bookkeeping does not cover these calls)
     ProfScope total(b, SDRXGPU_K_TOTAL);
 
     const float2 *src = (const float2 *)in;
@@ -1373,19 +1509,8 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
         size_t produced = 0;
         int rc;
         if (out_is_host) {
-            // kernels write the compact keep buffers; rows are copied out below
-            rc = run_chunk(b, n, nullptr, nullptr, b->keep_stride, 0, &produced);
+            rc = run_chunk_host(b, n, iq_out, audio_out, out_stride, produced_total, &produced);
             if (rc) return rc;
-            if (produced) {
-                if (iq_out)
-                    HIPCHK(hipMemcpy2DAsync((float2 *)iq_out + produced_total, out_stride * sizeof(float2), b->d_keep,
-                                            (size_t)b->keep_stride * sizeof(float2), produced * sizeof(float2), b->n_ch,
-                                            hipMemcpyDeviceToHost, b->stream));
-                if (audio_out)
-                    HIPCHK(hipMemcpy2DAsync((float *)audio_out + produced_total, out_stride * sizeof(float), b->d_audio_keep,
-                                            (size_t)b->keep_stride * sizeof(float), produced * sizeof(float), b->n_ch,
-                                            hipMemcpyDeviceToHost, b->stream));
-            }
         } else if (b->pipelined) {
             rc = run_chunk_pipelined(b, n, (float2 *)iq_out, (float *)audio_out, out_stride, &produced);
             if (rc) return rc;
@@ -1398,6 +1523,53 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
     }
     if (out_len) *out_len = produced_total;
     if (in_is_host || out_is_host) HIPCHK(hipStreamSynchronize(b->stream));   // borrowed buffers: done before return
+    return SDRXGPU_OK;                                                        // (the copy stream's work is ordered before the bank's: ev_d2h)
+}
+
+// Throughput entry for a caller that has the block in PAGE-LOCKED host memory and takes the outputs on the device:
+// nothing waits.  The H2D copy goes on the bank's copy stream into the input ring the kernels of the previous block
+// are NOT reading, so it runs beside them; this block's kernels follow on the bank's stream.
+extern "C" int sdrxgpu_bank_process_pinned(sdrxgpu_bank *b, const sdrxgpu_iq *iq_in, size_t in_len, void *d_iq_out,
+                                           void *d_audio_out, size_t out_stride, size_t *out_len)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "process_pinned: null bank");
+    if (in_len && !iq_in) return fail(SDRXGPU_ERR_INVALID_ARG, "process_pinned: null input");
+    if (b->pipelined) return fail(SDRXGPU_ERR_UNSUPPORTED, "process_pinned: not for pipelined banks");
+    if (b->mix && in_len > b->max_chunk)
+        return fail(SDRXGPU_ERR_UNSUPPORTED, "process_pinned: a bank with mix-down takes at most max_in_len = %u samples per call", b->max_chunk);
+    int rc = validate_call(b, in_len, d_iq_out || d_audio_out, out_stride);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(b->device));
+    if ((rc = ensure_copy_stream(b))) return rc;
+    if (b->h2d_pending) {       // the previous call's host buffer is the caller's again once this call has begun
+        HIPCHK(hipEventSynchronize(b->ev_h2d));
+        b->h2d_pending = false;
+    }
+    if (b->mix) b->mix_frames = 0;
+    ProfScope total(b, SDRXGPU_K_TOTAL);
+    const float2 *src = (const float2 *)iq_in;
+    size_t done = 0, produced_total = 0;
+    while (done < in_len) {
+        const int r = b->xr;
+        float2 *d_ingest = b->d_xr[r] + ((long long)b->n_in - b->x_origin);
+        const size_t n = std::min(in_len - done, (size_t)b->max_chunk);
+        // ring r was last read two chunks ago; if that was not under this entry (no event yet), wait for everything
+        // queued on the bank's stream so far
+        if (!b->ring_busy[r]) HIPCHK(hipEventRecord(b->ev_ring_free[r], b->stream));
+        HIPCHK(hipStreamWaitEvent(b->copy_stream, b->ev_ring_free[r], 0));
+        HIPCHK(hipMemcpyAsync(d_ingest, src + done, n * sizeof(float2), hipMemcpyHostToDevice, b->copy_stream));
+        HIPCHK(hipEventRecord(b->ev_h2d, b->copy_stream));
+        b->h2d_pending = true;
+        HIPCHK(hipStreamWaitEvent(b->stream, b->ev_h2d, 0));
+        size_t produced = 0;
+        rc = run_chunk(b, n, (float2 *)d_iq_out, (float *)d_audio_out, out_stride, produced_total, &produced);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(b->ev_ring_free[r], b->stream));
+        b->ring_busy[r] = true;
+        produced_total += produced;
+        done += n;
+    }
+    if (out_len) *out_len = produced_total;
     return SDRXGPU_OK;
 }
 

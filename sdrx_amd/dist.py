@@ -54,6 +54,80 @@ class BlockFanout:
         return self.buf
 
 
+class PipelinedFanout:
+    """Double-buffered fan-out: the broadcast of block k+1 runs beside the processing of block k.
+
+    ``bufs`` are the two receive buffers of this rank, used alternately (on GPUs: the bank's two input rings,
+    ``ChannelBank.ingest_buffer()`` and ``ingest_buffer_after()``, so that a block lands where the kernels read
+    it).  Per step k::
+
+        cur = fan.get(k)            # block k; the current stream waits for its broadcast, the host does not
+        fan.post(k + 1, nxt)        # rank src: start moving block k+1 (async, on the side stream)
+        ... enqueue the processing of cur ...
+        fan.done(k)                 # buffer k % 2 may be refilled once what was enqueued so far has run
+
+    With one rank nothing is communicated unless ``force`` (rehearsal of the RCCL path on one GPU).  ``gloo`` / CPU
+    tensors take the same calls (no streams; ``async_op`` broadcasts)."""
+
+    def __init__(self, dist, bufs, src=0, force=False, inline=False):
+        self.dist = dist
+        self.inline = inline        # A/B only: the broadcast of block k in line on the compute stream, at get(k)
+        self.bufs = list(bufs)
+        self.src = src
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.active = dist is not None and (self.world > 1 or force)
+        self.cuda = bool(self.bufs) and self.bufs[0].is_cuda
+        self._work = [None, None]
+        self._local = [None, None]
+        if self.active and self.cuda:
+            import torch
+            self._torch = torch
+            self.comm = torch.cuda.Stream()
+            self.free = [torch.cuda.Event(), torch.cuda.Event()]
+            for e in self.free:
+                e.record()
+
+    def post(self, k, block=None):
+        """Start moving block k into buffer k % 2; ``block`` is needed on rank ``src`` only."""
+        i = k & 1
+        if not self.active or self.inline:
+            self._local[i] = block
+            return
+        buf = self.bufs[i]
+        if self.cuda:
+            torch = self._torch
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(self.free[i])          # whoever read this buffer last is done with it
+                if self.rank == self.src:
+                    buf.copy_(block, non_blocking=True)
+                self._work[i] = self.dist.broadcast(buf, src=self.src, async_op=True)
+        else:
+            if self.rank == self.src:
+                buf.copy_(block)
+            self._work[i] = self.dist.broadcast(buf, src=self.src, async_op=True)
+
+    def get(self, k):
+        """Block k (posted earlier).  On GPUs the current stream waits for the broadcast, not the host."""
+        i = k & 1
+        if not self.active:
+            return self._local[i]
+        if self.inline:
+            if self.rank == self.src:
+                self.bufs[i].copy_(self._local[i])
+            self.dist.broadcast(self.bufs[i], src=self.src)
+            return self.bufs[i]
+        w, self._work[i] = self._work[i], None
+        if w is not None:
+            w.wait()
+        return self.bufs[i]
+
+    def done(self, k):
+        """Everything that reads buffer k % 2 has been enqueued on the current stream."""
+        if self.active and self.cuda:
+            self.free[k & 1].record()
+
+
 def max_over_ranks(dist, seconds: float, device="cpu") -> float:
     """Wall time of the slowest rank (the bench contract's timing)."""
     if dist is None or dist.get_world_size() == 1:

@@ -93,3 +93,35 @@ def test_two_rank_gloo_sharded_equals_unsharded(oracle, tmp_path):
     assert covered == n_ch
     assert np.array_equal(got_iq.view(np.uint32), ref_iq.view(np.uint32))
     assert np.array_equal(got_au.view(np.uint32), ref_au.view(np.uint32))
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks as child processes and relay rank 0's
+    JSON line (here: the CPU self-test of the launcher + double-buffered fan-out, gloo, no GPU work)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch", "--steps", "12"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12
+    assert d["selftest"]["blocks_received_wrong"] == 0
+    assert {"metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"} <= set(d)
+
+
+def test_pipelined_fanout_single_rank_passes_blocks_through():
+    """world == 1: nothing is communicated, block k comes back from get(k)."""
+    fan = sdist.PipelinedFanout(None, [torch.empty(4, 2), torch.empty(4, 2)])
+    blocks = [torch.full((4, 2), float(i)) for i in range(5)]
+    fan.post(0, blocks[0])
+    for k in range(5):
+        cur = fan.get(k)
+        if k + 1 < 5:
+            fan.post(k + 1, blocks[k + 1])
+        assert torch.equal(cur, blocks[k])
+        fan.done(k)

@@ -1,0 +1,144 @@
+"""The three entry points of the C ABI give the same bits: host pointers (sdrxgpu_bank_process, a large bank run as two
+channel halves with the D2H of the first beside the kernels of the second), device pointers
+(sdrxgpu_bank_process_device, blocks placed in the bank's two input rings) and page-locked host input with device
+outputs (sdrxgpu_bank_process_pinned, nothing waits)."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from sdrx_amd import bank as sb, chains, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _blocks(ch, n, seed=11, car=None):
+    L = ch.block_len
+    return [synth.synth_iq(seed, b * L, L, 0.25, car or [], [0.3] if car else [], ch.N, 10000) for b in range(n)]
+
+
+def _device_run(bank, blocks, n_ch, in_place):
+    L = len(blocks[0])
+    d_iq = torch.zeros(n_ch, 512, 2, device="cuda")
+    d_au = torch.zeros(n_ch, 512, device="cuda")
+    outs = []
+    for k, x in enumerate(blocks):
+        xt = torch.from_numpy(x.view(np.float32).reshape(L, 2).copy()).cuda()
+        if in_place:       # write the block where the bank expects it (its current input ring): no copy inside the call
+            p, cap = bank.ingest_buffer()
+            assert cap >= L
+            dst = torch.as_tensor(sb.DeviceView(p, (L, 2)), device="cuda")
+            dst.copy_(xt)
+            src = p
+        else:
+            src = xt.data_ptr()
+        torch.cuda.synchronize()
+        assert bank.process_device(src, L, d_iq.data_ptr(), d_au.data_ptr(), 512) == 512
+        bank.synchronize()
+        outs.append((d_iq.cpu().numpy().view(np.complex64)[..., 0].copy(), d_au.cpu().numpy().copy()))
+    return outs
+
+
+@pytest.mark.parametrize("n_ch,fused", [(2304, sb.FUSED_AUTO), (4100, sb.FUSED_OFF), (4100, sb.FUSED_REQUIRE)])
+def test_host_entry_in_two_halves_equals_device_entry(n_ch, fused):
+    ch = chains.chain("10")
+    offs = chains.offsets_cycled(n_ch, ch.N)
+    tabs = sb.translators_for(ch, offs)
+    blocks = _blocks(ch, 3, car=[tabs[7]])
+    kw = dict(block_hint=0xFFFFFFFF, tuning={"fused_tail": fused})
+    dev = sb.ChannelBank(tabs, ch.stage_tuples(), **kw)
+    want = _device_run(dev, blocks, n_ch, in_place=True)
+    dev.close()
+    host = sb.ChannelBank(tabs, ch.stage_tuples(), **kw)
+    iq = np.zeros((n_ch, 512), np.complex64)
+    au = np.zeros((n_ch, 512), np.float32)
+    for k, x in enumerate(blocks):
+        if k == 1:          # audio only: no IQ rows cross PCIe
+            a, b = host.process(x, audio_out=au)
+            assert a is None
+        else:
+            a, b = host.process(x, iq_out=iq, audio_out=au)
+            assert np.array_equal(a.view(np.uint32), want[k][0].view(np.uint32))
+        assert np.array_equal(b.view(np.uint32), want[k][1].view(np.uint32))
+    info = host.info()
+    assert info.samples_in == 3 * ch.block_len and info.samples_out == 3 * 512
+    # ragged calls through the same entry still agree with one long call
+    host.reset()
+    x = np.concatenate(blocks[:2])
+    parts = [host.process(x[a:b]) for a, b in ((0, 1000), (1000, 320625), (320625, 320625), (320625, len(x)))]
+    got = np.concatenate([p[0] for p in parts], axis=1)
+    assert np.array_equal(got[:, :512].view(np.uint32), want[0][0].view(np.uint32))
+    assert np.array_equal(got[:, 512:].view(np.uint32), want[1][0].view(np.uint32))
+    host.close()
+
+
+def test_process_pinned_equals_device_entry_and_two_banks_overlap():
+    ch = chains.chain("10")
+    offs = chains.offsets_for_config("c3")
+    tabs = sb.translators_for(ch, offs)
+    n_ch, L = len(offs), ch.block_len
+    streams = [_blocks(ch, 4, seed=21 + i) for i in range(2)]
+    want = []
+    for blocks in streams:
+        bank = sb.ChannelBank(tabs, ch.stage_tuples())
+        want.append(_device_run(bank, blocks, n_ch, in_place=False))
+        bank.close()
+    banks = [sb.ChannelBank(tabs, ch.stage_tuples()) for _ in streams]
+    # the device layer's double buffer (airspy_dev.cpp:410-414): two page-locked blocks per stream, used in turn
+    hosts = [[torch.empty(L, 2).pin_memory() for _ in range(2)] for _ in streams]
+    outs = [[(torch.zeros(n_ch, 512, 2, device="cuda"), torch.zeros(n_ch, 512, device="cuda")) for _ in range(4)] for _ in streams]
+
+    def drive(i):
+        for k, x in enumerate(streams[i]):
+            hosts[i][k & 1].copy_(torch.from_numpy(x.view(np.float32).reshape(L, 2)))
+            n = banks[i].process_pinned(hosts[i][k & 1].data_ptr(), L, outs[i][k][0].data_ptr(), outs[i][k][1].data_ptr(), 512)
+            assert n == 512
+        banks[i].synchronize()
+
+    th = [threading.Thread(target=drive, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        for k in range(4):
+            got_iq = outs[i][k][0].cpu().numpy().view(np.complex64)[..., 0]
+            got_au = outs[i][k][1].cpu().numpy()
+            assert np.array_equal(got_iq.view(np.uint32), want[i][k][0].view(np.uint32)), (i, k)
+            assert np.array_equal(got_au.view(np.uint32), want[i][k][1].view(np.uint32)), (i, k)
+        # mixing the entries on one bank stays right: one more block through the host entry
+        a, b = banks[i].process(streams[i][0])
+        assert a.shape == (n_ch, 512)
+        banks[i].close()
+
+
+def test_blocks_placed_in_both_input_rings_ahead_of_time():
+    """sdrxgpu_bank_ingest_buffer / _after: block k+1 is written into the bank's other ring BEFORE block k is processed."""
+    ch = chains.chain("10")
+    offs = [0, 9, -250, 599]
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    blocks = _blocks(ch, 4, seed=5)
+    ref = sb.ChannelBank(tabs, ch.stage_tuples())
+    want = [ref.process(x) for x in blocks]
+    ref.close()
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    d_iq = torch.zeros(len(offs), 512, 2, device="cuda")
+    d_au = torch.zeros(len(offs), 512, device="cuda")
+    p_cur, _ = bank.ingest_buffer()
+    torch.as_tensor(sb.DeviceView(p_cur, (L, 2)), device="cuda").copy_(torch.from_numpy(blocks[0].view(np.float32).reshape(L, 2).copy()))
+    for k in range(4):
+        if k + 1 < 4:
+            p_next = bank.ingest_buffer_after(L)
+            assert p_next != p_cur
+            torch.as_tensor(sb.DeviceView(p_next, (L, 2)), device="cuda").copy_(
+                torch.from_numpy(blocks[k + 1].view(np.float32).reshape(L, 2).copy()))
+        torch.cuda.synchronize()
+        assert bank.process_device(p_cur, L, d_iq.data_ptr(), d_au.data_ptr(), 512) == 512
+        bank.synchronize()
+        assert bank.ingest_buffer()[0] == p_next or k == 3
+        assert np.array_equal(d_iq.cpu().numpy().view(np.complex64)[..., 0].view(np.uint32), want[k][0].view(np.uint32))
+        assert np.array_equal(d_au.cpu().numpy().view(np.uint32), want[k][1].view(np.uint32))
+        p_cur = p_next
+    bank.close()
