@@ -96,6 +96,8 @@ typedef struct {
     uint32_t tail_tile;      /* final outputs per workgroup of the separate tail kernel, 8..128; 0 = auto     */
     uint32_t tail_generic;   /* 1 = run-time-tap tail kernel even where a compile-time one exists             */
     uint32_t fused_tail;     /* 0 = auto; 1 = never run stage 3 inside the stage-1/2 kernel; 2 = require it   */
+    uint32_t host_parts;     /* channel parts of sdrxgpu_bank_process (D2H of one beside the kernels of the next):
+                                0 = auto, 1..8                                                                */
 } sdrxgpu_tuning;
 
 typedef struct {

@@ -45,7 +45,7 @@ class AgcParams(C.Structure):
 
 class Tuning(C.Structure):
     """sdrxgpu_tuning: geometry / kernel-path overrides for tests and tuning runs (0 = automatic)."""
-    _fields_ = [(k, C.c_uint32) for k in ("k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail")]
+    _fields_ = [(k, C.c_uint32) for k in ("k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail", "host_parts")]
 
 
 FUSED_AUTO, FUSED_OFF, FUSED_REQUIRE = 0, 1, 2

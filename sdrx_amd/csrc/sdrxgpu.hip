@@ -267,7 +267,8 @@ struct sdrxgpu_bank {
     // host entries: copies on their own stream beside the kernels (sdrxgpu_bank_process: D2H of the first channel half
     // beside the kernels of the second; sdrxgpu_bank_process_pinned: H2D of block k+1 beside the kernels of block k)
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_part[2] = {nullptr, nullptr};       // kernels of a channel half are done
+    int host_parts = 0;                               // tuning.host_parts (0 = auto)
+    hipEvent_t ev_part[8] = {};                       // kernels of a channel part are done
     hipEvent_t ev_h2d = nullptr;                      // the block is in the input ring
     hipEvent_t ev_d2h = nullptr;                      // the output rows have left the keep buffers
     hipEvent_t ev_ring_free[2] = {nullptr, nullptr};  // the kernels that read input ring r are done
@@ -319,7 +320,9 @@ static void free_bank(sdrxgpu_bank *b)
         (void)hipStreamSynchronize(b->copy_stream);
         (void)hipStreamDestroy(b->copy_stream);
     }
-    for (hipEvent_t e : {b->ev_part[0], b->ev_part[1], b->ev_h2d, b->ev_d2h, b->ev_ring_free[0], b->ev_ring_free[1]})
+    for (hipEvent_t e : {b->ev_h2d, b->ev_d2h, b->ev_ring_free[0], b->ev_ring_free[1]})
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b->ev_part)
         if (e) (void)hipEventDestroy(e);
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
@@ -509,6 +512,11 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         b->tile_b = (int)tune.tail_tile;
     }
     b->tail_generic = tune.tail_generic != 0;
+    if (tune.host_parts > 8) {
+        free_bank(b);
+        return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.host_parts %u (0..8)", tune.host_parts);
+    }
+    b->host_parts = (int)tune.host_parts;
     {
         const int tB = (int)b->ntaps[cfg->n_stages - 1], mB = (int)b->m[cfg->n_stages - 1];
         size_t np, nr = 0;
@@ -1419,8 +1427,9 @@ static int ensure_copy_stream(sdrxgpu_bank *b)
 {
     if (b->copy_stream) return SDRXGPU_OK;
     HIPCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
-    for (hipEvent_t *e : {&b->ev_part[0], &b->ev_part[1], &b->ev_h2d, &b->ev_d2h, &b->ev_ring_free[0], &b->ev_ring_free[1]})
+    for (hipEvent_t *e : {&b->ev_h2d, &b->ev_d2h, &b->ev_ring_free[0], &b->ev_ring_free[1]})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t &e : b->ev_part) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return SDRXGPU_OK;
 }
 
@@ -1440,15 +1449,16 @@ static int run_chunk_host(sdrxgpu_bank *b, size_t in_len, void *iq_out, void *au
     const int gsz = b->W * b->CPW;
     const int unit = gsz / gcd_int(gsz, kWave) * kWave;                 // whole channel groups and whole k_agc blocks
     const bool copies = n_b > 0 && (iq_out || audio_out);
-    int mid = (int)b->n_ch;
-    if (copies && !b->squelch && !b->fir_T && !b->mix && b->n_ch >= 2048) {
-        mid = (((int)b->n_ch / 2 + unit - 1) / unit) * unit;
-        if (mid >= (int)b->n_ch) mid = (int)b->n_ch;
-    }
-    const int n_parts = mid < (int)b->n_ch ? 2 : 1;
+    int n_parts = 1;
+    // measured at 10 000 channels, page-locked buffers (ms per block): 1 part 2.26, 2: 1.85, 3: 1.73, 4: 1.68, 5: 1.69, 8: 1.79
+    // (smaller parts fill the chip less well); automatic: about 2 500 channels per part, at most 4 parts
+    if (copies && !b->squelch && !b->fir_T && !b->mix && b->n_ch >= 2048)
+        n_parts = b->host_parts ? b->host_parts : std::min(4, std::max(1, (int)(b->n_ch / 2500)));
+    const int per = (((int)b->n_ch + n_parts - 1) / n_parts + unit - 1) / unit * unit;   // channels per part
+    n_parts = ((int)b->n_ch + per - 1) / per;
     if (n_parts > 1 && (rc = ensure_copy_stream(b))) return rc;
     for (int p = 0; p < n_parts; p++) {
-        const int ch_lo = p ? mid : 0, ch_hi = (p == n_parts - 1) ? (int)b->n_ch : mid;
+        const int ch_lo = p * per, ch_hi = std::min((int)b->n_ch, ch_lo + per);
         if ((rc = launch_k12_range(b, &job, b->stream, ch_lo / gsz, (ch_hi + gsz - 1) / gsz))) return rc;
         size_t prod = 0;
         if ((rc = launch_tail(b, &job, nullptr, nullptr, b->keep_stride, 0, &prod, ch_lo, ch_hi, p == n_parts - 1))) return rc;
