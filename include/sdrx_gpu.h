@@ -172,6 +172,21 @@ void sdrxgpu_agc_params_sdrx(sdrxgpu_agc_params *agc, sdrxgpu_agc_params *lf_agc
  * t[n] = exp(complex<float>(0, float(-2*pi*n*ch_offset*z/N))), n = 0..N-1. */
 int sdrxgpu_make_translator(int N, int z, int ch_offset, sdrxgpu_iq *out);
 
+/* ---- channel names -> translator offsets (host-side set-up; no GPU involved) -------------------------------
+ * Aeronautical channel name "NNN.NNN" (8.33 kHz and 25 kHz schemes share one grid: 12 steps per 100 kHz, the last
+ * two digits name the step, src/sdrx.cpp:1456-1466) -> frequency in Hz, as parse_fq(str, true) of
+ * src/sdrx.cpp:957-1021.  SDRXGPU_ERR_INVALID_ARG for anything parse_fq answers with 0. */
+int sdrxgpu_parse_channel(const char *name, uint32_t *fq_hz);
+/* Tuner centre frequency sdrx picks for a set of channels: midpoint of the lowest and the highest channel
+ * (by name order, Channel::operator<, src/sdrx.cpp:212), rounded to the nearest 100 kHz (src/sdrx.cpp:1398-1408). */
+int sdrxgpu_tuner_fq(const char *const *names, size_t n, uint32_t *tuner_fq);
+/* channel_to_offset of src/sdrx.cpp:1449-1478: signed number of 8.33 kHz steps of the channel from the tuner
+ * centre -- the ch_offset that sdrxgpu_make_translator takes. */
+int sdrxgpu_channel_to_offset(const char *name, int32_t tuner_fq, int *offset);
+/* verify_requested_bandwidth of src/sdrx.cpp:1424-1443: *fits = 1 iff highest - lowest channel <= 80 % of the sample
+ * rate (what sdrx refuses to start without --bw-override, src/sdrx.cpp:1560-1564). */
+int sdrxgpu_channels_fit_bandwidth(const char *const *names, size_t n, uint32_t sample_rate_hz, int *fits);
+
 /* Replaces the per-channel set-up of src/sdrx.cpp:1680-1714 (MSD ctor msd.hpp:54-68). */
 int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out_bank);
 

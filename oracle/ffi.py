@@ -122,6 +122,31 @@ class _Lib:
     def fir2(self, taps, gain_db=None):
         return _FIR(self, taps, gain_db, stereo=True)
 
+    # ---- channel names -> offsets (restatement only: static code of sdrx.cpp) -----
+    def parse_fq(self, s, aeronautical=True):
+        assert self.prefix == "sdrx_oracle"
+        f = self.lib.sdrx_oracle_parse_fq
+        f.restype, f.argtypes = C.c_uint32, [C.c_char_p, C.c_int]
+        return int(f(s.encode(), int(aeronautical)))
+
+    def channel_to_offset(self, name, tuner_fq):
+        assert self.prefix == "sdrx_oracle"
+        f = self.lib.sdrx_oracle_channel_to_offset
+        f.restype, f.argtypes = C.c_int, [C.c_char_p, C.c_int32]
+        return int(f(name.encode(), tuner_fq))
+
+    def tuner_fq(self, names):
+        assert self.prefix == "sdrx_oracle"
+        f = self.lib.sdrx_oracle_tuner_fq
+        f.restype, f.argtypes = C.c_uint32, [C.POINTER(C.c_char_p), C.c_size_t]
+        return int(f((C.c_char_p * len(names))(*[n.encode() for n in names]), len(names)))
+
+    def verify_bandwidth(self, names, sample_rate_hz):
+        assert self.prefix == "sdrx_oracle"
+        f = self.lib.sdrx_oracle_verify_bandwidth
+        f.restype, f.argtypes = C.c_int, [C.POINTER(C.c_char_p), C.c_size_t, C.c_uint32]
+        return bool(f((C.c_char_p * len(names))(*[n.encode() for n in names]), len(names), sample_rate_hz))
+
     # ---- stereo mix-down (restatement only: static code of sdrx.cpp) -----
     def audio_pos(self, channel_no, num_channels):
         assert self.prefix == "sdrx_oracle"

@@ -798,3 +798,105 @@ void sdrx_oracle_synth_iq(uint64_t seed, uint64_t n_start, size_t n, float noise
         out_iq[2 * i + 1] = im;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Channel names -> offsets.  Restated from the text of sdrx.cpp (static functions of the ALSA
+ * program; not compilable here): parse_fq :957-1021, tuner frequency :1398-1408,
+ * verify_requested_bandwidth :1424-1443, channel_to_offset :1449-1478.
+ * ------------------------------------------------------------------------------------------ */
+#include <ctype.h>
+
+static int oracle_sub_channel(const char *two, int *step, unsigned *hz)
+{
+    /* the two sub_ch_map tables (sdrx.cpp:984-989 frequencies, :1461-1466 steps), same keys */
+    static const char *const keys[16] = {"00", "05", "10", "15", "25", "30", "35", "40", "50", "55", "60", "65", "75", "80", "85", "90"};
+    static const int steps[16] = {0, 0, 1, 2, 3, 3, 4, 5, 6, 6, 7, 8, 9, 9, 10, 11};
+    static const unsigned hzs[16] = {0, 0, 8333, 16667, 25000, 25000, 33333, 41667, 50000, 50000, 58333, 66667, 75000, 75000, 83333, 91667};
+    for (int i = 0; i < 16; i++)
+        if (strncmp(keys[i], two, 2) == 0 && two[2] == 0) {
+            *step = steps[i];
+            *hz = hzs[i];
+            return 1;
+        }
+    return 0;
+}
+
+uint32_t sdrx_oracle_parse_fq(const char *str, int aeronautical)        /* sdrx.cpp:957-1021 */
+{
+    uint32_t fq = 0;
+    unsigned mhz = 0, hz = 0;
+    const char *dot = strchr(str, '.');
+    if (!dot) return 0;                                                  /* :966 */
+    const size_t n_int = (size_t)(dot - str), n_frac = strlen(dot + 1);
+    for (size_t i = 0; i < n_int; i++)
+        if (!isdigit((unsigned char)str[i])) return 0;
+    for (size_t i = 0; i < n_frac; i++)
+        if (!isdigit((unsigned char)dot[1 + i])) return 0;
+    if (n_int < 2 || n_int > 4 || n_frac == 0 || n_frac > 6) return 0;   /* :972-976 */
+    if (aeronautical && n_frac != 3) return 0;                           /* :979 */
+    char int_str[8];
+    memcpy(int_str, str, n_int);
+    int_str[n_int] = 0;
+    if (aeronautical) {
+        int step;
+        unsigned sub;
+        if (oracle_sub_channel(dot + 2, &step, &sub)) {                  /* :990-994 */
+            mhz = (unsigned)atol(int_str);
+            hz = (unsigned)(dot[1] - '0') * 100000 + sub;
+        }
+    } else {
+        static const unsigned mult[6] = {100000, 10000, 1000, 100, 10, 1};
+        mhz = (unsigned)atol(int_str);
+        for (size_t i = 0; i < n_frac; i++) hz += (unsigned)(dot[1 + i] - '0') * mult[i];   /* :997-1006 */
+    }
+    if (mhz < 4000) fq = mhz * 1000000 + hz;                             /* :1014-1016 */
+    return fq;
+}
+
+int sdrx_oracle_channel_to_offset(const char *channel, int32_t tuner_fq)   /* sdrx.cpp:1449-1478 */
+{
+    const char *dot = strchr(channel, '.');
+    char int_str[16];
+    const size_t n_int = (size_t)(dot - channel);
+    memcpy(int_str, channel, n_int);
+    int_str[n_int] = 0;
+    const char *frac_str = dot + 1;
+    int step = 0;
+    unsigned hz;
+    oracle_sub_channel(frac_str + 1, &step, &hz);                        /* sub_ch_map.find(frac_str.substr(1)) */
+    int32_t fq_base = (int32_t)(atol(int_str) * 1000000);
+    fq_base += (frac_str[0] - '0') * 100000;
+    const int32_t fq_diff = fq_base - tuner_fq;
+    const int32_t offset_diff = (fq_diff / 100000) * 12;
+    return offset_diff + step;
+}
+
+static void oracle_lo_hi(const char *const *names, size_t n, const char **lo, const char **hi)
+{
+    /* std::sort of the Channel vector = lexicographic order of the names (sdrx.cpp:212) */
+    *lo = *hi = names[0];
+    for (size_t i = 1; i < n; i++) {
+        if (strcmp(names[i], *lo) < 0) *lo = names[i];
+        if (strcmp(names[i], *hi) > 0) *hi = names[i];
+    }
+}
+
+uint32_t sdrx_oracle_tuner_fq(const char *const *names, size_t n)        /* sdrx.cpp:1398-1408 */
+{
+    const char *lo, *hi;
+    oracle_lo_hi(names, n, &lo, &hi);
+    const double lo_fq = (double)sdrx_oracle_parse_fq(lo, 1), hi_fq = (double)sdrx_oracle_parse_fq(hi, 1);
+    const double mid_fq = lo_fq + (hi_fq - lo_fq) / 2;
+    const double mid_fq_rounded = round(mid_fq / 100000.0) * 100000.0;
+    return (uint32_t)mid_fq_rounded;
+}
+
+int sdrx_oracle_verify_bandwidth(const char *const *names, size_t n, uint32_t sample_rate_hz)   /* sdrx.cpp:1424-1443 */
+{
+    const char *lo, *hi;
+    oracle_lo_hi(names, n, &lo, &hi);
+    const uint32_t lo_fq = sdrx_oracle_parse_fq(lo, 1), hi_fq = sdrx_oracle_parse_fq(hi, 1);
+    const uint32_t ch_bw = hi_fq - lo_fq;
+    const uint32_t iq_bw = sample_rate_hz * 8 / 10;                       /* 80% of sample rate */
+    return ch_bw <= iq_bw;
+}

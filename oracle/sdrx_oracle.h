@@ -129,6 +129,18 @@ void  sdrx_oracle_pan_mix(const float *audio, size_t stride, const int *pos, int
 /* float -> S16 with the clamp of sdrx.cpp:649-656 */
 void  sdrx_oracle_to_s16(const float *in, size_t n, int16_t *out);
 
+/* ---- channel names -> translator offsets (static functions of sdrx.cpp, restated from the text: PARITY UNPINNED
+ * beyond review -- sdrx.cpp cannot be compiled here; integer logic with hand-checked known answers in
+ * tests/test_oracle.py) ---- */
+/* parse_fq, reference src/sdrx.cpp:957-1021 (0 for an invalid string; aeronautical != 0: channel-name notation) */
+uint32_t sdrx_oracle_parse_fq(const char *str, int aeronautical);
+/* channel_to_offset, reference src/sdrx.cpp:1449-1478 (name must be a valid aeronautical channel) */
+int      sdrx_oracle_channel_to_offset(const char *channel, int32_t tuner_fq);
+/* tuner frequency for a set of channels, reference src/sdrx.cpp:1398-1408 */
+uint32_t sdrx_oracle_tuner_fq(const char *const *names, size_t n);
+/* verify_requested_bandwidth, reference src/sdrx.cpp:1424-1443 (without the override flag) */
+int      sdrx_oracle_verify_bandwidth(const char *const *names, size_t n, uint32_t sample_rate_hz);
+
 /* ---- synthetic IQ generator (ours; not a reference function) ---- */
 void sdrx_oracle_synth_iq(uint64_t seed, uint64_t n_start, size_t n, float noise_amp,
                           int n_carriers, const float *const *carrier_tables_iq, int N,

@@ -116,6 +116,10 @@ def load_library():
     L.sdrxgpu_agc_params_sdrx.restype = None
     L.sdrxgpu_agc_params_sdrx.argtypes = [C.POINTER(AgcParams), C.POINTER(AgcParams)]
     L.sdrxgpu_make_translator.argtypes = [C.c_int, C.c_int, C.c_int, vp]
+    L.sdrxgpu_parse_channel.argtypes = [C.c_char_p, C.POINTER(C.c_uint32)]
+    L.sdrxgpu_tuner_fq.argtypes = [C.POINTER(C.c_char_p), sz, C.POINTER(C.c_uint32)]
+    L.sdrxgpu_channel_to_offset.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int)]
+    L.sdrxgpu_channels_fit_bandwidth.argtypes = [C.POINTER(C.c_char_p), sz, C.c_uint32, C.POINTER(C.c_int)]
     L.sdrxgpu_bank_create.argtypes = [C.POINTER(_Cfg), C.POINTER(vp)]
     L.sdrxgpu_bank_destroy.argtypes = [vp]
     L.sdrxgpu_bank_reset.argtypes = [vp]
@@ -142,7 +146,8 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "sdrxgpu_agc_params_sdrx", "sdrxgpu_make_translator", "sdrxgpu_bank_create", "sdrxgpu_bank_destroy",
+    "sdrxgpu_agc_params_sdrx", "sdrxgpu_make_translator", "sdrxgpu_parse_channel", "sdrxgpu_tuner_fq",
+    "sdrxgpu_channel_to_offset", "sdrxgpu_channels_fit_bandwidth", "sdrxgpu_bank_create", "sdrxgpu_bank_destroy",
     "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_process_pinned", "sdrxgpu_bank_flush", "sdrxgpu_bank_ingest_buffer", "sdrxgpu_bank_ingest_buffer_after",
     "sdrxgpu_host_register", "sdrxgpu_host_unregister", "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_get_squelch", "sdrxgpu_bank_profile_enable",
     "sdrxgpu_audio_pos", "sdrxgpu_bank_get_mix", "sdrxgpu_bank_mix_buffers",
@@ -179,6 +184,41 @@ def make_translator(N: int, z: int, ch_offset: int) -> np.ndarray:
     out = np.empty(N, dtype=np.complex64)
     _check(load_library().sdrxgpu_make_translator(N, z, ch_offset, out.ctypes.data), "sdrxgpu_make_translator")
     return out
+
+
+def _names(names):
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    return arr, len(names)
+
+
+def parse_channel(name: str) -> int:
+    """Aeronautical channel name -> Hz (``parse_fq(str, true)``, sdrx.cpp:957-1021); raises on an invalid name."""
+    fq = C.c_uint32()
+    _check(load_library().sdrxgpu_parse_channel(name.encode(), C.byref(fq)), "sdrxgpu_parse_channel")
+    return fq.value
+
+
+def tuner_fq(names) -> int:
+    """Tuner centre sdrx picks for these channels (sdrx.cpp:1398-1408)."""
+    arr, n = _names(names)
+    fq = C.c_uint32()
+    _check(load_library().sdrxgpu_tuner_fq(arr, n, C.byref(fq)), "sdrxgpu_tuner_fq")
+    return fq.value
+
+
+def channel_to_offset(name: str, tuner: int) -> int:
+    """Signed 8.33 kHz steps from the tuner centre (``channel_to_offset``, sdrx.cpp:1449-1478)."""
+    off = C.c_int()
+    _check(load_library().sdrxgpu_channel_to_offset(name.encode(), tuner, C.byref(off)), "sdrxgpu_channel_to_offset")
+    return off.value
+
+
+def channels_fit_bandwidth(names, sample_rate_hz: int) -> bool:
+    """The 80 % rule of ``verify_requested_bandwidth`` (sdrx.cpp:1424-1443)."""
+    arr, n = _names(names)
+    fits = C.c_int()
+    _check(load_library().sdrxgpu_channels_fit_bandwidth(arr, n, sample_rate_hz, C.byref(fits)), "sdrxgpu_channels_fit_bandwidth")
+    return bool(fits.value)
 
 
 def translators_for(chain, offsets):

@@ -97,6 +97,112 @@ extern "C" int sdrxgpu_make_translator(int N, int z, int ch_offset, sdrxgpu_iq *
 }
 
 // ------------------------------------------------------------------------------------------
+// channel names -> offsets (reference src/sdrx.cpp:957-1021, 1398-1408, 1424-1478)
+// ------------------------------------------------------------------------------------------
+// the step (0..11) and the frequency inside a 100 kHz band that the last two digits of a channel name stand for
+// (sub_ch_map, sdrx.cpp:984-989 and 1461-1466: both tables, one row per key)
+static bool sub_channel(const char *two, int *step, unsigned *hz)
+{
+    static const struct { const char *key; int step; unsigned hz; } map[] = {
+        {"00", 0, 0},      {"05", 0, 0},      {"10", 1, 8333},   {"15", 2, 16667},
+        {"25", 3, 25000},  {"30", 3, 25000},  {"35", 4, 33333},  {"40", 5, 41667},
+        {"50", 6, 50000},  {"55", 6, 50000},  {"60", 7, 58333},  {"65", 8, 66667},
+        {"75", 9, 75000},  {"80", 9, 75000},  {"85", 10, 83333}, {"90", 11, 91667}};
+    for (const auto &e : map)
+        if (e.key[0] == two[0] && e.key[1] == two[1]) {
+            if (step) *step = e.step;
+            if (hz) *hz = e.hz;
+            return true;
+        }
+    return false;
+}
+
+// "NNN.NNN": 2-4 digits, a dot, exactly three digits, a known pair at the end (parse_fq's aeronautical branch)
+static bool split_channel(const char *name, long *mhz, int *tenth, const char **two)
+{
+    if (!name) return false;
+    const char *dot = strchr(name, '.');
+    if (!dot) return false;
+    const size_t nint = (size_t)(dot - name), nfrac = strlen(dot + 1);
+    if (nint < 2 || nint > 4 || nfrac != 3) return false;
+    for (const char *p = name; *p; p++)
+        if (p != dot && (*p < '0' || *p > '9')) return false;
+    *mhz = atol(std::string(name, nint).c_str());
+    *tenth = dot[1] - '0';
+    *two = dot + 2;
+    return sub_channel(*two, nullptr, nullptr);
+}
+
+extern "C" int sdrxgpu_parse_channel(const char *name, uint32_t *fq_hz)
+{
+    long mhz;
+    int tenth;
+    const char *two;
+    unsigned hz = 0;
+    if (!fq_hz || !split_channel(name, &mhz, &tenth, &two) || mhz >= 4000)
+        return fail(SDRXGPU_ERR_INVALID_ARG, "parse_channel: '%s' is not an aeronautical channel name", name ? name : "(null)");
+    sub_channel(two, nullptr, &hz);
+    *fq_hz = (uint32_t)(mhz * 1000000 + tenth * 100000 + (long)hz);     // sdrx.cpp:990-994, 1014-1016
+    return SDRXGPU_OK;
+}
+
+static int lowest_highest(const char *const *names, size_t n, uint32_t *lo_fq, uint32_t *hi_fq)
+{
+    if (!names || n == 0) return fail(SDRXGPU_ERR_INVALID_ARG, "no channels");
+    // std::sort over Channel::operator< = std::string order of the names (sdrx.cpp:212, 1398-1401)
+    std::string lo = names[0] ? names[0] : "", hi = lo;
+    for (size_t i = 0; i < n; i++) {
+        if (!names[i]) return fail(SDRXGPU_ERR_INVALID_ARG, "null channel name");
+        const std::string s = names[i];
+        if (s < lo) lo = s;
+        if (hi < s) hi = s;
+    }
+    int rc;
+    if ((rc = sdrxgpu_parse_channel(lo.c_str(), lo_fq)) || (rc = sdrxgpu_parse_channel(hi.c_str(), hi_fq))) return rc;
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_tuner_fq(const char *const *names, size_t n, uint32_t *tuner_fq)
+{
+    uint32_t lo, hi;
+    if (!tuner_fq) return fail(SDRXGPU_ERR_INVALID_ARG, "tuner_fq: null argument");
+    const int rc = lowest_highest(names, n, &lo, &hi);
+    if (rc) return rc;
+    const double lo_fq = (double)lo, hi_fq = (double)hi;
+    const double mid_fq = lo_fq + (hi_fq - lo_fq) / 2;                    // sdrx.cpp:1403-1408
+    *tuner_fq = (uint32_t)(std::round(mid_fq / 100000.0) * 100000.0);
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_channel_to_offset(const char *name, int32_t tuner_fq, int *offset)
+{
+    long mhz;
+    int tenth, step = 0;
+    const char *two;
+    if (!offset || !split_channel(name, &mhz, &tenth, &two))
+        return fail(SDRXGPU_ERR_INVALID_ARG, "channel_to_offset: '%s' is not an aeronautical channel name", name ? name : "(null)");
+    sub_channel(two, &step, nullptr);
+    int32_t fq_base = (int32_t)(mhz * 1000000);                           // sdrx.cpp:1470-1475, int32 arithmetic as there
+    fq_base += tenth * 100000;
+    const int32_t fq_diff = fq_base - tuner_fq;
+    const int32_t offset_diff = (fq_diff / 100000) * 12;
+    *offset = offset_diff + step;
+    return SDRXGPU_OK;
+}
+
+extern "C" int sdrxgpu_channels_fit_bandwidth(const char *const *names, size_t n, uint32_t sample_rate_hz, int *fits)
+{
+    uint32_t lo, hi;
+    if (!fits) return fail(SDRXGPU_ERR_INVALID_ARG, "channels_fit_bandwidth: null argument");
+    const int rc = lowest_highest(names, n, &lo, &hi);
+    if (rc) return rc;
+    const uint32_t ch_bw = hi - lo;
+    const uint32_t iq_bw = sample_rate_hz * 8 / 10;                       // 80 % of the sample rate, sdrx.cpp:1437 (uint32, as there)
+    *fits = ch_bw <= iq_bw ? 1 : 0;
+    return SDRXGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // stage-1/2 kernel registry: one entry per (M1,T1,M2,T2) the library was built for
 // ------------------------------------------------------------------------------------------
 struct K12Launch {

@@ -2,14 +2,23 @@
 // MSD / DS (reference src/sdrx.cpp:327-346, set-up 1680-1714) and checks every output against the
 // oracle (oracle/sdrx_oracle.h).  Test program: built and run by tests/test_gpu_adapter.py on the GPU box.
 //
-//   adapter_data_cb <taps.txt> <n_channels> <n_blocks> <serial|ds|serial_direct|ds_direct|broken_direct>
+//   adapter_data_cb <taps.txt> <n_channels> <n_blocks> <serial|ds|pool|serial_direct|ds_direct|pool_direct|broken_direct>
+//
+// pool: the USE_THREAD_POOL build of sdrx (CMakeLists.txt:104-113): data_cb submits one lambda per channel to a pool of
+// worker threads (src/sdrx.cpp:331-335, the pool is src/tp.hpp:31-78) -- here a 4-thread pool of this test's own -- and
+// waits on the latch.  Its outputs must equal the serial loop's bit for bit.
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <latch>
 #include <memory>
+#include <mutex>
+#include <queue>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sdrx_gpu_adapter.hpp"
@@ -18,6 +27,54 @@
 using sdrxgpu::iqsample_t;
 
 #define CH_IQ_BUF_SIZE 512   // reference src/sdrx.cpp:129
+
+// A pool of worker threads taking std::function jobs from one queue: the shape of the reference's ThreadPool
+// (submit() + N workers, src/tp.hpp:31-78), written for this test.
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned n)
+    {
+        for (unsigned i = 0; i < n; i++) workers_.emplace_back([this] { run(); });
+    }
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            done_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void submit(std::function<void()> job)
+    {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            jobs_.push(std::move(job));
+        }
+        cv_.notify_one();
+    }
+
+private:
+    void run()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [this] { return done_ || !jobs_.empty(); });
+                if (jobs_.empty()) return;
+                job = std::move(jobs_.front());
+                jobs_.pop();
+            }
+            job();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::queue<std::function<void()>> jobs_;
+    std::vector<std::thread> workers_;
+    bool done_ = false;
+};
 
 struct Channel {            // the hot-path members of sdrx's Channel (sdrx.cpp:207-234)
     int ch_offset;
@@ -56,6 +113,7 @@ int main(int argc, char **argv)
     const int n_ch = std::atoi(argv[2]), n_blocks = std::atoi(argv[3]);
     const std::string mode = argv[4];
     const bool use_threaded_ds = mode == "ds" || mode == "ds_direct";
+    const bool use_pool = mode == "pool" || mode == "pool_direct";
     const bool direct = mode.find("direct") != std::string::npos;
     const bool broken = mode == "broken_direct";      // promises a chunk layout, then hands out other pointers
     if (direct) sdrxgpu::chunk_stride() = CH_IQ_BUF_SIZE;
@@ -110,6 +168,16 @@ int main(int argc, char **argv)
     }
     sdrx_oracle_bank *ob = sdrx_oracle_bank_create(n_ch, tptr.data(), tlen.data(), n_stages, m.data(), nt.data(), taps.data(), 0, 0);
 
+    // pool modes: the same channels once more as a second bank, driven by the plain serial loop, for the bitwise comparison
+    // (an empty call on every channel first: it closes the first bank, so that the MSDs built next form a bank of their own)
+    std::vector<Channel> serial_channels(use_pool ? n_ch : 0);
+    if (use_pool)
+        for (auto &ch : channels) ch.msd.decimate(nullptr, 0, nullptr);
+    for (int c = 0; c < (int)serial_channels.size(); c++) serial_channels[c].msd = sdrxgpu::MSD(tables[c], stages, false);
+    std::vector<iqsample_t> serial_iq((size_t)serial_channels.size() * CH_IQ_BUF_SIZE);
+    std::unique_ptr<WorkerPool> pool(use_pool ? new WorkerPool(4) : nullptr);
+    bool pool_equals_serial = true;
+
     std::vector<iqsample_t> data(block_len), ring((size_t)2 * n_ch * (CH_IQ_BUF_SIZE + 8)), ref_iq((size_t)n_ch * CH_IQ_BUF_SIZE);
     std::vector<float> ref_audio((size_t)n_ch * CH_IQ_BUF_SIZE);
     double worst_iq = 0, worst_audio = 0;
@@ -121,7 +189,24 @@ int main(int argc, char **argv)
         // --- the loop of data_cb, sdrx.cpp:327-346, verbatim in shape ---
         iqsample_t *const chunk = ring.data() + (size_t)(blk & 1) * n_ch * (CH_IQ_BUF_SIZE + 8);   // chunks alternate, like a ring
         iqsample_t *iq_buf_ptr = chunk;
-        if (use_threaded_ds) {
+        if (use_pool) {
+            for (size_t c = 0; c < serial_channels.size(); c++)
+                serial_channels[c].msd.decimate(data.data(), data_len, serial_iq.data() + c * CH_IQ_BUF_SIZE);
+            auto latch = std::make_shared<std::latch>(channels.size());
+            for (auto &ch : channels) {
+                const iqsample_t *d = data.data();
+                pool->submit([&ch, d, data_len, out = iq_buf_ptr, latch]() {      // sdrx.cpp:331-335
+                    ch.msd.decimate(d, data_len, out);
+                    latch->count_down();
+                });
+                iq_buf_ptr += pitch;
+            }
+            latch->wait();
+            for (int c = 0; c < n_ch; c++)
+                if (std::memcmp(chunk + (size_t)c * pitch, serial_iq.data() + (size_t)c * CH_IQ_BUF_SIZE, CH_IQ_BUF_SIZE * sizeof(iqsample_t)) != 0 ||
+                    std::memcmp(channels[c].msd.audio(), serial_channels[c].msd.audio(), CH_IQ_BUF_SIZE * sizeof(float)) != 0)
+                    pool_equals_serial = false;
+        } else if (use_threaded_ds) {
             auto latch = std::make_shared<std::latch>(channels.size());
             for (auto &ch : channels) {
                 ch.ds_ptr->addJob(data.data(), data_len, iq_buf_ptr, latch);
@@ -152,10 +237,12 @@ int main(int argc, char **argv)
     sdrx_oracle_bank_destroy(ob);
     // a broken promise is reported (sticky error) and the rows still end up where the caller asked for them
     const bool err_ok = broken ? !sdrxgpu::last_error().empty() : sdrxgpu::last_error().empty();
-    const bool ok = err_ok && worst_iq <= 1e-5 && worst_audio <= 1e-5;
+    const bool ok = err_ok && worst_iq <= 1e-5 && worst_audio <= 1e-5 && pool_equals_serial;
     std::printf("%s: mode=%s channels=%d blocks=%d rel_err iq=%.3e audio=%.3e %s\n", ok ? "PASS" : "FAIL", argv[4], n_ch, n_blocks,
                 worst_iq, worst_audio, sdrxgpu::last_error().c_str());
+    pool.reset();
     channels.clear();
+    serial_channels.clear();
     sdrxgpu::shutdown();
     return ok ? 0 : 1;
 }

@@ -33,7 +33,7 @@ def adapter_bin(tmp_path_factory):
     return exe, taps
 
 
-@pytest.mark.parametrize("mode", ["serial", "ds", "serial_direct", "ds_direct", "broken_direct"])
+@pytest.mark.parametrize("mode", ["serial", "ds", "pool", "serial_direct", "ds_direct", "pool_direct", "broken_direct"])
 def test_data_cb_loop_through_adapter(adapter_bin, mode):
     exe, taps = adapter_bin
     r = subprocess.run([exe, taps, "33", "3", mode], capture_output=True, text=True, timeout=300)
