@@ -265,6 +265,11 @@ int sdrxgpu_bank_mix_buffers(sdrxgpu_bank *bank, void **d_mix_f32, void **d_mix_
 /* AGC gains per channel (what sdrx prints with -v, sdrx.cpp:593-634); either may be NULL. */
 int sdrxgpu_bank_get_gains(sdrxgpu_bank *bank, float *agc_gain, float *lf_agc_gain);
 
+/* The complete AGC state per channel: gain_ and power_ of AGC and of LfAGC (agc.hpp:71-78, 133-141) -- the only
+ * recurrence state of the path; with samples_in of sdrxgpu_bank_get_info it says where a channel stands.  Any
+ * pointer may be NULL. */
+int sdrxgpu_bank_get_agc_state(sdrxgpu_bank *bank, float *agc_gain, float *agc_power, float *lf_gain, float *lf_power);
+
 /* Kernel timing with HIP events recorded on the bank's own stream.
  * kernel: 0 = mixer + stages 1-2, 1 = remaining stages, 2 = AGC/demod, 3 = whole process call. */
 #define SDRXGPU_K_STAGE12 0

@@ -134,6 +134,7 @@ def load_library():
     L.sdrxgpu_bank_ingest_buffer_after.argtypes = [vp, sz, C.POINTER(vp)]
     L.sdrxgpu_bank_get_info.argtypes = [vp, C.POINTER(BankInfo)]
     L.sdrxgpu_bank_get_gains.argtypes = [vp, vp, vp]
+    L.sdrxgpu_bank_get_agc_state.argtypes = [vp, vp, vp, vp, vp]
     L.sdrxgpu_bank_get_squelch.argtypes = [vp, vp, vp]
     L.sdrxgpu_audio_pos.argtypes = [C.c_uint, C.c_uint]
     L.sdrxgpu_bank_get_mix.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
@@ -149,7 +150,7 @@ EXPORTED_SYMBOLS = [
     "sdrxgpu_agc_params_sdrx", "sdrxgpu_make_translator", "sdrxgpu_parse_channel", "sdrxgpu_tuner_fq",
     "sdrxgpu_channel_to_offset", "sdrxgpu_channels_fit_bandwidth", "sdrxgpu_bank_create", "sdrxgpu_bank_destroy",
     "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_process_pinned", "sdrxgpu_bank_flush", "sdrxgpu_bank_ingest_buffer", "sdrxgpu_bank_ingest_buffer_after",
-    "sdrxgpu_host_register", "sdrxgpu_host_unregister", "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_get_squelch", "sdrxgpu_bank_profile_enable",
+    "sdrxgpu_host_register", "sdrxgpu_host_unregister", "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_get_agc_state", "sdrxgpu_bank_get_squelch", "sdrxgpu_bank_profile_enable",
     "sdrxgpu_audio_pos", "sdrxgpu_bank_get_mix", "sdrxgpu_bank_mix_buffers",
     "sdrxgpu_bank_profile_read", "sdrxgpu_bank_profile_reset", "sdrxgpu_strerror", "sdrxgpu_last_error",
     "sdrxgpu_version",
@@ -358,6 +359,12 @@ class ChannelBank:
         b = np.empty(self.n_channels, dtype=np.float32)
         _check(self._L.sdrxgpu_bank_get_gains(self._h, a.ctypes.data, b.ctypes.data), "sdrxgpu_bank_get_gains")
         return a, b
+
+    def agc_state(self):
+        """(agc gain, agc power, lf gain, lf power), each [n_ch]: the whole recurrence state of the path."""
+        a = [np.empty(self.n_channels, dtype=np.float32) for _ in range(4)]
+        _check(self._L.sdrxgpu_bank_get_agc_state(self._h, *[v.ctypes.data for v in a]), "sdrxgpu_bank_get_agc_state")
+        return tuple(a)
 
     def squelch_state(self):
         """(snr_db[n_ch], state[n_ch]) after the last chunk (sdrx.cpp:567-573)."""

@@ -1025,6 +1025,22 @@ extern "C" int sdrxgpu_bank_get_gains(sdrxgpu_bank *b, float *agc_gain, float *l
     return SDRXGPU_OK;
 }
 
+extern "C" int sdrxgpu_bank_get_agc_state(sdrxgpu_bank *b, float *agc_gain, float *agc_power, float *lf_gain, float *lf_power)
+{
+    if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_agc_state: null bank");
+    HIPCHK(hipSetDevice(b->device));
+    std::vector<float4> st(b->n_ch);
+    HIPCHK(hipMemcpyAsync(st.data(), b->d_state, st.size() * sizeof(float4), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (uint32_t c = 0; c < b->n_ch; c++) {
+        if (agc_gain) agc_gain[c] = st[c].x;
+        if (agc_power) agc_power[c] = st[c].y;
+        if (lf_gain) lf_gain[c] = st[c].z;
+        if (lf_power) lf_power[c] = st[c].w;
+    }
+    return SDRXGPU_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // profiling (HIP events on the bank's own stream)
 // ------------------------------------------------------------------------------------------

@@ -91,3 +91,17 @@ def regen_blocks(g):
         blocks.append(x[p:p + n])
         p += n
     return ch, blocks
+
+
+def margin(name, **errs):
+    """Record the worst relative error a parity test observed (printed with -s; collected into
+    gpurun_out/parity_margins.jsonl on the GPU box and summarised under profiles/)."""
+    import json
+    rec = {"test": name, **{k: float(v) for k, v in errs.items()}}
+    print("margin", json.dumps(rec))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_margins.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass

@@ -3,7 +3,7 @@ alsa_write_cb, src/sdrx.cpp:469-497 + 646-656, with get_audio_pos (1024-1044) fo
 import numpy as np
 import pytest
 
-from conftest import RTOL
+from conftest import RTOL, margin
 from sdrx_amd import bank as sb, chains, synth
 
 pytestmark = pytest.mark.gpu
@@ -40,6 +40,7 @@ def test_mix_fir2_s16_end_to_end_vs_oracle(oracle):
     ref_msd = [oracle.msd(t, ch.stage_tuples()) for t in tabs]
     ref_fir = oracle.fir2(taps, 6.0)
     nonzero = 0
+    worst = 0.0
     for b, x in enumerate(blocks):
         _, au = bank.process(x)
         mix_f, mix_q = bank.mix()
@@ -48,11 +49,14 @@ def test_mix_fir2_s16_end_to_end_vs_oracle(oracle):
         r_q = oracle.to_s16(r_mix)
         assert mix_f.shape == (512, 2) and mix_q.shape == (512, 2)
         scale = max(float(np.sqrt(np.mean(r_mix ** 2))), 1e-3)
-        assert float(np.max(np.abs(mix_f - r_mix))) / scale <= 2e-5, b
+        e = float(np.max(np.abs(mix_f - r_mix))) / scale
+        worst = max(worst, e)
+        assert e <= RTOL, (b, e)
         assert int(np.max(np.abs(mix_q.astype(np.int32) - r_q.astype(np.int32)))) <= 1, b     # truncation at an integer edge
         assert np.array_equal(mix_q, oracle.to_s16(mix_f)), b                              # conversion itself: exact
         nonzero += int(np.any(mix_q != 0))
     assert nonzero >= 3
+    margin("mix_end_to_end_with_squelch", mix=worst)
     bank.close()
 
 
@@ -122,7 +126,9 @@ def test_mix_with_ragged_calls_and_reset(oracle):
             want = fir.filter(oracle.pan_mix(au, pos)) if au.shape[1] else np.zeros((0, 2), np.float32)
             if au.shape[1]:
                 scale = max(float(np.sqrt(np.mean(want ** 2))), 1e-3)
-                assert float(np.max(np.abs(mix_f - want))) / scale <= 2e-5
+                e = float(np.max(np.abs(mix_f - want))) / scale
+                margin("mix_ragged_calls", mix=e)
+                assert e <= RTOL, e
     run()
     bank.reset()
     run()

@@ -5,7 +5,7 @@ identical seeded input.  Tolerance: 1e-5 relative under the comparator of confte
 import numpy as np
 import pytest
 
-from conftest import RTOL, load_golden, regen_blocks, rel_err, rel_err_rows
+from conftest import RTOL, load_golden, margin, regen_blocks, rel_err, rel_err_rows
 from sdrx_amd import bank as sb
 from sdrx_amd import chains, synth
 
@@ -39,7 +39,7 @@ def _run_golden(name, lf_agc=False, **bank_kw):
                                   "g4_fs10000_tone", "g1_fs2400_c1"])
 def test_golden_vectors(name):
     worst_iq, worst_au, _ = _run_golden(name)
-    print(f"{name}: iq rel {worst_iq:.3e}  audio rel {worst_au:.3e}")
+    margin(f"golden[{name}]", iq=worst_iq, audio=worst_au)
     assert worst_iq <= RTOL
     assert worst_au <= RTOL
 
@@ -444,6 +444,7 @@ def test_squelch_and_gated_audio_vs_oracle(oracle):
     ref_ch = [offi.SquelchChannel(oracle, lv, win, pb, ru, rd) for lv in levels]
     ref_msd = [oracle.msd(t, ch.stage_tuples()) for t in tabs]
     seen_states = set()
+    w_iq = w_snr = w_au = 0.0
     for b, x in enumerate(blocks):
         iq, au = bank.process(x)
         snr, st = bank.squelch_state()
@@ -451,11 +452,16 @@ def test_squelch_and_gated_audio_vs_oracle(oracle):
             y = ref_msd[c].decimate(x)
             r_au, r_snr, r_st = ref_ch[c].chunk(y)
             assert rel_err(iq[c], y) <= RTOL
+            # SNR in dB from single-precision power sums over ~90 / ~90 FFT bins (GPU: radix-2 fp32 FFT; oracle: the DFT
+            # in double): 2e-3 dB = 4.6e-4 relative on a ratio of two sums whose terms each carry ~1e-6
             assert abs(float(snr[c]) - r_snr) < 2e-3, (b, c, snr[c], r_snr)
             assert int(st[c]) == r_st, (b, c)
             scale = max(float(np.sqrt(np.mean(r_au ** 2))), 1e-3)
-            assert float(np.max(np.abs(au[c] - r_au))) / scale <= 2e-5, (b, c)
+            e_au = float(np.max(np.abs(au[c] - r_au))) / scale
+            w_iq, w_snr, w_au = max(w_iq, rel_err(iq[c], y)), max(w_snr, abs(float(snr[c]) - r_snr)), max(w_au, e_au)
+            assert e_au <= RTOL, (b, c, e_au)
         seen_states.add((int(st[0]), bool(np.any(au[0] != 0))))
+    margin("squelch_and_gated_audio", iq=w_iq, snr_db=w_snr, audio=w_au)
     assert (1, True) in seen_states and (0, False) in seen_states and (0, True) in seen_states   # open, closed, ramp-down
     assert np.all(bank.squelch_state()[1][[1]] == 1)       # level 0: always open
     # whole chunks only

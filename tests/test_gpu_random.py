@@ -3,7 +3,7 @@ flags, against the oracle's per-channel chain (MSD -> AGC -> |.| -> LfAGC [-> FI
 import numpy as np
 import pytest
 
-from conftest import RTOL, rel_err
+from conftest import RTOL, margin, rel_err
 from sdrx_amd import bank as sb, chains, synth
 
 pytestmark = pytest.mark.gpu
@@ -43,6 +43,7 @@ def test_random_configuration_vs_oracle(oracle, seed):
     iq = np.concatenate(iq_parts, axis=1)
     au = np.concatenate(au_parts, axis=1)
     assert iq.shape[1] == total // ch.m_total
+    w_iq = w_au = 0.0
     for c in rng.choice(n_ch, size=min(n_ch, 4), replace=False):
         msd = oracle.msd(tabs[c], ch.stage_tuples(), ftfir)
         y = msd.decimate(x)
@@ -50,5 +51,9 @@ def test_random_configuration_vs_oracle(oracle, seed):
         a = agc.adjust_lf(oracle.demod_am(agc.adjust(y)))
         if fir is not None:
             a = oracle.fir(fir, 0.0).filter(a)
-        assert rel_err(iq[c], y) <= RTOL, (seed, c, rel_err(iq[c], y))
-        assert rel_err(au[c], a) <= 2 * RTOL, (seed, c, rel_err(au[c], a))
+        w_iq, w_au = max(w_iq, rel_err(iq[c], y)), max(w_au, rel_err(au[c], a))
+    margin(f"random[{seed}] rate={ch.rate} lf={int(lf)} ftfir={int(ftfir)} fir={int(fir is not None)}", iq=w_iq, audio=w_au)
+    # An ACTIVE LF AGC amplifies rounding (two builds of the reference itself drift apart by 1.7e-5 within 5 blocks and 4e-3
+    # within 16, tests/test_oracle.py::test_active_lf_agc_is_ill_conditioned_in_the_reference_itself; worst seen here over
+    # these 1.2 - 2.6 blocks: 1.06e-5): twice the tolerance for those cases only
+    assert w_iq <= RTOL and w_au <= (2 * RTOL if lf else RTOL), (seed, w_iq, w_au)

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, load_golden, regen_blocks, rel_err
+from conftest import GOLD, RTOL, load_golden, regen_blocks, rel_err, rel_err_rows
 from sdrx_amd import chains, synth
 
 ALL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
@@ -278,3 +278,38 @@ def test_fm_demod_restatement_vs_float64(oracle):
     assert float(np.abs(y[1:] - want).max()) < 5e-7
     xn = x[-1].astype(np.complex128) / abs(x[-1].astype(np.complex128))
     assert abs(prev[0] - xn.real) < 1e-6 and abs(prev[1] - xn.imag) < 1e-6
+
+
+def test_active_lf_agc_is_ill_conditioned_in_the_reference_itself(oracle):
+    """Why long-stream AUDIO parity with --lf-agc cannot be held to 1e-5 by anybody: two builds of the same code that
+    differ only in rounding (FMA contraction, vector width) -- the reference's own portable and AVX2 builds where they
+    exist here, and always the oracle's plain and -O3 -march builds -- agree on the decimated IQ to ~1e-6 for ever, and on
+    the audio to ~1e-6 for ever WITHOUT the LF AGC (sdrx's default), but drift apart on noise-only channels once the LF
+    AGC is active (attack 1.0 on a power estimate of the envelope: a feedback loop that amplifies rounding).  So
+    tests/test_gpu_long_stream.py holds the audio to 1e-5 over 200 blocks with the LF AGC inactive and, with it active,
+    checks each block starting from the state the GPU was in (sdrxgpu_bank_get_agc_state)."""
+    from oracle import ffi
+    ch = chains.chain("10")
+    offs = [0, 599, 37, -77]
+    tabs = [oracle.make_translator(ch.N, ch.z, o) if o else None for o in offs]
+    car = [tabs[1]]
+    L = ch.block_len
+    pairs = [("oracle -O2 vs -O3 -march", oracle, ffi.load("oracle_fast"), True)]
+    if ffi.have_ref():
+        pairs.append(("reference portable vs AVX2", ffi.load("ref_portable"), ffi.load("ref_avx2"), False))
+    for label, A, B, is_oracle in pairs:
+        for lf in (False, True):
+            mk = (lambda lib: lib.bank(tabs, ch.stage_tuples(), use_lf_agc=lf)) if is_oracle else (lambda lib: lib.bank(tabs, ch.stage_tuples(), False, lf))
+            a, b = mk(A), mk(B)
+            worst_iq = worst_au = 0.0
+            for k in range(16):
+                x = synth.synth_iq(2024, k * L, L, 0.25, car, [0.3], ch.N, 10000)
+                (ia, aa), (ib, ab) = a.process(x, threads=4), b.process(x, threads=4)
+                worst_iq = max(worst_iq, rel_err_rows(ib, ia))
+                worst_au = max(worst_au, rel_err_rows(ab, aa))
+            print(f"{label}, lf_agc={lf}: 16 blocks, iq {worst_iq:.2e}, audio {worst_au:.2e}")
+            assert worst_iq <= RTOL
+            if lf:
+                assert worst_au > 10 * RTOL      # the two builds of ONE code base are > 1e-4 apart
+            else:
+                assert worst_au <= RTOL
