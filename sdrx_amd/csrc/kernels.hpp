@@ -212,6 +212,37 @@ __device__ __forceinline__ void folded_fir2_steps(v2f &acc0, v2f &acc1, const v2
     }
 }
 
+// Three outputs at once: with three alternating chains no packed FMA reads the result of the one before it, so no wait
+// state at all.  Per output the same instruction sequence on the same operands as folded_fir_unrolled.
+template <int K>
+__device__ __forceinline__ void fma_tap3(v2f &a0, v2f &a1, v2f &a2, const v2f x0, const v2f x1, const v2f x2, const v2f hpair)
+{
+    if constexpr ((K & 1) == 0)
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %3, %6, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %4, %6, %1 op_sel_hi:[1,0,1]\n\t"
+            "v_pk_fma_f32 %2, %5, %6, %2 op_sel_hi:[1,0,1]"
+            : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(x0), "v"(x1), "v"(x2), "s"(hpair));
+    else
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %1, %4, %6, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+            "v_pk_fma_f32 %2, %5, %6, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+            : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(x0), "v"(x1), "v"(x2), "s"(hpair));
+}
+
+template <int T, int NH, int I = 0>
+__device__ __forceinline__ void folded_fir3_steps(v2f &a0, v2f &a1, v2f &a2, const v2f *__restrict__ w0, const v2f *__restrict__ w1,
+                                                  const v2f *__restrict__ w2, const float (&h)[NH])
+{
+    static_assert(NH % 2 == 0 && NH >= (T + 1) / 2, "tap array: an even number of entries covering h[0 .. (T-1)/2]");
+    constexpr int half = (T - 1) >> 1;
+    if constexpr (I <= half) {
+        const v2f hp = {h[I & ~1], h[(I & ~1) + 1]};
+        if constexpr (I < half)
+            fma_tap3<I>(a0, a1, a2, w0[I] + w0[T - 1 - I], w1[I] + w1[T - 1 - I], w2[I] + w2[T - 1 - I], hp);
+        else
+            fma_tap3<I>(a0, a1, a2, w0[half], w1[half], w2[half], hp);
+        folded_fir3_steps<T, NH, I + 1>(a0, a1, a2, w0, w1, w2, h);
+    }
+}
+
 // Two outputs whose windows w0 and w1 both lie in LDS (any distance apart): nothing is shared between them but the
 // taps and the instruction slots -- the point is the alternating accumulation chains of fma_tap2.
 template <int T, int NH>
@@ -532,58 +563,61 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
         __syncthreads();
         const v2f *__restrict__ lds2 = reinterpret_cast<const v2f *>(lds);
         constexpr int NT = kWave * W;
-        const int n_half = (n_int + 1) >> 1;                 // a lane takes outputs kp and kp + n_half of one channel
-        const float rcp_half = __builtin_amdgcn_rcpf((float)max(n_half, 1));
+        // Every instruction here competes for issue slots with two other workgroups' main loops (the CU's vector issue
+        // is 86 % busy), so what does not depend on the channel is computed once: the lanes' LDS-DMA source offsets
+        // (the first NS of them kept in registers) and the lanes' window offsets.
         const float rcp_seg = __builtin_amdgcn_rcpf((float)seg_y2);
+        auto source_offset = [&](int d0) -> uint32_t {       // LDS piece d0 + lane (samples 2d, 2d+1 in time order) <- where k_stage12 stored it
+            const int tt = 2 * min(d0 + lane, npc - 1);
+            const int seg = (int)(((float)tt + 0.5f) * rcp_seg);
+            const int rem = tt - seg * seg_y2;
+            return (uint32_t)((((rem / Y2B) * SPW + seg) * Y2B + (rem % Y2B)) * 8);
+        };
+        constexpr int NS = 8;
+        uint32_t soff[NS];
+#pragma unroll
+        for (int k = 0; k < NS; k++) soff[k] = source_offset(k * kWave);
+        const int n_third = (n_int + 2) / 3;                 // a lane takes outputs kp, kp + n_third, kp + 2 n_third of one channel
         const float2 *__restrict__ ysrc = y2_out + a.y2_hist + base;
         for (int cp0 = 0; cp0 < W * CPW; cp0 += cpp) {
             const int ncp = min(cpp, W * CPW - cp0);
             const int chb = cg * W * CPW + cp0;              // first channel of this pass
             // The range of each channel comes back by LDS-DMA, 1 KB per instruction, landing in TIME order (row ci =
-            // rlen samples): LDS piece d of a row (samples 2d, 2d+1) is fetched from where k_stage12 stored them,
-            // (body*SPW + segment)*Y2B + q.  A wave's lanes keep their source offset for all channels it fetches.
-            for (int d0 = 0; d0 < npc; d0 += kWave) {
-                const int d = min(d0 + lane, npc - 1);
-                const int tt = 2 * d;
-                const int seg = (int)(((float)tt + 0.5f) * rcp_seg);
-                const int rem = tt - seg * seg_y2;
-                const uint32_t soff = (uint32_t)((((rem / Y2B) * SPW + seg) * Y2B + (rem % Y2B)) * 8);
-                if (d0 + lane < npc) {
-                    for (int ci = wave; ci < ncp; ci += W) {
-                        const char *g = reinterpret_cast<const char *>(ysrc + (size_t)min(chb + ci, a.n_ch - 1) * a.y2_stride) + soff;
-                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)g, (lds_void *)(uint32_t)(uintptr_t)(lds + ((size_t)ci * rlen + 2 * d0) * 8),
-                                                         16, 0, 0);
-                    }
+            // rlen samples); wave w fetches channels w, w + W, ... of the pass
+            for (int ci = wave; ci < ncp; ci += W) {
+                const char *grow = reinterpret_cast<const char *>(ysrc + (size_t)min(chb + ci, a.n_ch - 1) * a.y2_stride);
+                char *lrow = lds + (size_t)ci * rlen * 8;
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    if (k * kWave < npc && k * kWave + lane < npc)
+                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + soff[k]), (lds_void *)(uint32_t)(uintptr_t)(lrow + k * kWave * 16), 16, 0, 0);
+                }
+                for (int d0 = NS * kWave; d0 < npc; d0 += kWave) {
+                    if (d0 + lane < npc)
+                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + source_offset(d0)), (lds_void *)(uint32_t)(uintptr_t)(lrow + (size_t)d0 * 16), 16, 0, 0);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            // the first and the last TA-1 outputs of every range, compactly, for k_tail4's boundary outputs
-            {
-                constexpr int SE = 2 * (TA - 1);
-                for (int i = tid; i < ncp * SE; i += NT) {
-                    const int ci = i / SE, e = i - ci * SE;
-                    if (chb + ci < a.n_ch) {
-                        const v2f v = lds2[ci * rlen + (e < TA - 1 ? e : rlen - SE + e)];
-                        seam_out[(size_t)(chb + ci) * a.seam_stride + g * SE + e] = make_float2(v.x, v.y);
-                    }
-                }
-            }
-            // interior outputs: lane = (channel, kp), outputs kp and kp + n_half (conflict-free 40-byte lane stride)
-            const int n_work = (n_int > 0) ? ncp * n_half : 0;
-            for (int idx = tid; idx < n_work; idx += NT) {
-                const int ci = (int)(((float)idx + 0.5f) * rcp_half);
-                const int kp = idx - ci * n_half;
+            for (int ci = wave; ci < ncp; ci += W) {
                 const int chn = chb + ci;
-                const bool second = kp + n_half < n_int;
-                const int rrA = rr_lo + kp, rrB = second ? rrA + n_half : rrA;
-                const v2f *__restrict__ wrow = lds2 + ci * rlen + (a.c0 - (TA - 1) - base);
-                v2f r0, r1;
-                folded_fir2_lds<TA>(r0, r1, wrow + MA * rrA, wrow + MA * rrB, taps.h3);
-                if (chn < a.n_ch) {
-                    float2 *__restrict__ y3row = y3_out + (size_t)chn * a.y3_stride;
-                    y3row[rrA] = make_float2(r0.x, r0.y);
-                    if (second) y3row[rrB] = make_float2(r1.x, r1.y);
+                if (chn >= a.n_ch) break;
+                const v2f *__restrict__ lrow = lds2 + ci * rlen;
+                // the first and the last TA-1 outputs of the range, compactly, for k_tail4's boundary outputs
+                constexpr int SE = 2 * (TA - 1);
+                if (lane < SE) seam_out[(size_t)chn * a.seam_stride + g * SE + lane] = *reinterpret_cast<const float2 *>(&lrow[lane < TA - 1 ? lane : rlen - SE + lane]);
+                static_assert(SE <= kWave, "seam entries of one range: one per lane");
+                // interior outputs, three per lane (conflict-free 40-byte lane stride, three alternating accumulation chains)
+                float2 *__restrict__ y3row = y3_out + (size_t)chn * a.y3_stride + rr_lo;
+                const v2f *__restrict__ wrow = lrow + (MA * rr_lo + a.c0 - (TA - 1) - base);
+                for (int kp = lane; kp < n_third; kp += kWave) {
+                    const bool has1 = kp + n_third < n_int, has2 = kp + 2 * n_third < n_int;
+                    const int k1 = has1 ? kp + n_third : kp, k2 = has2 ? kp + 2 * n_third : kp;
+                    v2f r0 = {0.f, 0.f}, r1 = {0.f, 0.f}, r2 = {0.f, 0.f};
+                    folded_fir3_steps<TA>(r0, r1, r2, wrow + MA * kp, wrow + MA * k1, wrow + MA * k2, taps.h3);
+                    y3row[kp] = make_float2(r0.x, r0.y);
+                    if (has1) y3row[k1] = make_float2(r1.x, r1.y);
+                    if (has2) y3row[k2] = make_float2(r2.x, r2.y);
                 }
             }
             __syncthreads();
