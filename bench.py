@@ -43,6 +43,7 @@ def parse_args(argv=None):
     ap.add_argument("--rate", default="10")
     ap.add_argument("--block-hint", type=int, default=0)
     ap.add_argument("--fused", type=int, default=0, help="tuning.fused_tail: 0 auto, 1 separate tail kernel, 2 require the fused path")
+    ap.add_argument("--pair", type=int, default=0, help="tuning.pair_lanes: 0 auto, 1 one channel per lane, 2 require two channels per lane")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--pipelined", action="store_true",
@@ -323,14 +324,16 @@ def main():
                          for b in range(n_ring)])
         ring = torch.from_numpy(host).cuda()
 
-    tuning = {"fused_tail": args.fused} if args.fused else None
+    tuning = {"fused_tail": args.fused, "pair_lanes": args.pair} if (args.fused or args.pair) else None
     fused_seen = {}
+    pair_seen = {}
 
     def run(offsets, steps, warmup):
         tabs = sb.translators_for(ch, offsets)
         bank = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, stream=tstream.cuda_stream, block_hint=args.block_hint,
                               pipelined=args.pipelined, tuning=tuning)
         fused_seen[len(offsets)] = int(bank.info().fused_tail)
+        pair_seen[len(offsets)] = int(bank.info().pair_lanes)
         # N > 1: the broadcasts land directly in the bank's two input rings, alternately (their addresses repeat
         # for whole blocks), so process_device finds each block in place; any other address would be copied in
         p0, cap = bank.ingest_buffer()
@@ -468,8 +471,9 @@ def main():
                 "parallelism": f"channel-sharded over {world} RCCL rank(s)" +
                                (", block k+1 broadcast over xGMI into the banks' other input ring while block k is processed"
                                 if (world > 1 or args.force_dist) else ""),
-                "kernel_path": "stage 3 fused behind stages 1-2 (k_stage12 + k_tail4 + k_agc)" if fused else
-                               "separate tail (k_stage12 + k_tail_s + k_agc)",
+                "kernel_path": ("stage 3 fused behind stages 1-2 (k_stage12 + k_tail4 + k_agc)" if fused else
+                                "separate tail (k_stage12 + k_tail_s + k_agc)") +
+                               (f"; two channels per lane in k_stage12, {pair_seen[n_ch] - 1} conjugate pairs share the mixer" if pair_seen[n_ch] else ""),
                 "realtime_factor": value * 1e6 / (n_ch * world * ch.fs),
                 "settle_steps": SETTLE_STEPS,    # untimed, before the W warm-up steps (clock settling, see time_bank)
                 "call_semantics": "drop-in: call k returns block k" if not args.pipelined else

@@ -98,6 +98,8 @@ typedef struct {
     uint32_t fused_tail;     /* 0 = auto; 1 = never run stage 3 inside the stage-1/2 kernel; 2 = require it   */
     uint32_t host_parts;     /* channel parts of sdrxgpu_bank_process (D2H of one beside the kernels of the next):
                                 0 = auto, 1..8                                                                */
+    uint32_t pair_lanes;     /* two channels per lane of the stage-1/2 kernel (conjugate partners share the mixer):
+                                0 = auto, 1 = never, 2 = require                                              */
 } sdrxgpu_tuning;
 
 typedef struct {
@@ -161,7 +163,7 @@ typedef struct {
     uint64_t samples_out;      /* outputs produced per channel since create/reset */
     uint64_t device_bytes;     /* HBM held by the bank */
     uint32_t fused_tail;       /* 1: stage 3 runs inside the stage-1/2 kernel (large banks of the 4-stage chains) */
-    uint32_t reserved;
+    uint32_t pair_lanes;       /* > 0: two channels per lane in the stage-1/2 kernel; the number of conjugate pairs + 1 */
 } sdrxgpu_bank_info;
 
 /* Fill the AGC / LfAGC parameter blocks as sdrx configures them per channel

@@ -626,6 +626,346 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
 }
 
 // ------------------------------------------------------------------------------------------
+// k_stage12p: k_stage12 with TWO channels per lane ("slot" = a pair of channels).
+//
+// The two channels of a lane share the input samples (one LDS read serves both) and, when their translator tables
+// are complex conjugates of each other -- channels at +k and -k steps from the tuner centre: sdrx.cpp:1687 gives
+// exp(j*float(phase)) and exp(j*float(-phase)), and libm's sincosf is exactly odd/even -- also the translator reads and
+// half of the mixer: x*t and x*conj(t) are P + {-xi*ti, xr*ti} and P + {xi*ti, -xr*ti} with the same P = {xr*tr, xi*tr},
+// three packed instructions for the two products instead of four.  Each channel's values come out of the same
+// instruction sequence on the same operands as in k_stage12 (bit-identical, tested).  The price is registers: two
+// delay-line sets per lane, two waves per SIMD instead of three -- with two independent channels per wave the
+// instruction streams interleave as well as three single-channel waves did.
+//   CONJ = true : slot = (channel, its conjugate partner or none); one translator row per slot
+//   CONJ = false: slot = any two channels (or one); two translator rows per slot
+// slots[s] = {channel A, channel B or -1}; lanes of a wave = CPW slots x SPW segments as in k_stage12.
+// ------------------------------------------------------------------------------------------
+// x[e]*t[e] and x[e]*conj(t[e]) for e = 0..4: 15 packed instructions, every dependent pair five instructions apart
+__device__ __forceinline__ void cmul5_conj_pk(const v2f (&x)[5], const v2f (&t)[5], v2f *outA, v2f *outB)
+{
+    v2f a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
+    asm("v_pk_mul_f32 %5, %10, %15 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %6, %11, %16 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %7, %12, %17 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %8, %13, %18 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %9, %14, %19 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %10, %15, %5 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %11, %16, %6 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %2, %12, %17, %7 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %3, %13, %18, %8 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %4, %14, %19, %9 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %5, %10, %15, %5 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %6, %11, %16, %6 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %7, %12, %17, %7 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %8, %13, %18, %8 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %9, %14, %19, %9 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "s_nop 0"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]));
+    outA[0] = a0; outA[1] = a1; outA[2] = a2; outA[3] = a3; outA[4] = a4;
+    outB[0] = b0; outB[1] = b1; outB[2] = b2; outB[3] = b3; outB[4] = b4;
+}
+
+template <int SB, int W, int CPW, int TR>
+struct TileGeomP {
+    static constexpr int row_bytes = SB * 8 + 16;
+    static constexpr int x_rows = kWave / CPW;
+    static constexpr int t_rows = TR * W * CPW;              // TR translator rows per slot
+    static constexpr int buf_bytes = (x_rows + t_rows) * row_bytes;
+};
+
+struct PairArgs {
+    const int2 *slots;       // [n_slots] {channel A, channel B or -1}
+    int n_slots;
+    int lds_bytes;           // dynamic LDS of the launch (>= 2 tile buffers; the rest is room for the stage-3 epilogue)
+};
+
+template <int T1, int T2, int Y2B, int W, int CPW, bool CONJ, int MA = 0, int TA = 1>
+__global__ __launch_bounds__(kWave * W, 2)
+void k_stage12p(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
+                float2 *__restrict__ y3_out, float2 *__restrict__ seam_out, const Stage12Args a, const PairArgs pa,
+                const Stage12Taps<T1, T2, TA> taps)
+{
+    constexpr int M1 = 5, M2 = 5;                          // (the 10 MS/s chain: cmul5_conj_pk)
+    constexpr int SB = M1 * M2 * Y2B;
+    constexpr int NY1 = M2 * Y2B;
+    constexpr int HALO = M1 * (T2 - M2) + (T1 - M1);
+    constexpr int WU = (HALO + SB - 1) / SB;
+    constexpr int C1 = T1 - M1;
+    constexpr int C2 = T2 - M2;
+    constexpr int TR = CONJ ? 1 : 2;
+    using G = TileGeomP<SB, W, CPW, TR>;
+    constexpr int SPW = kWave / CPW;
+    static_assert(WU == 1, "one warm-up body");
+
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int csub = lane / SPW;
+    const int sl = lane - csub * SPW;
+
+    const int xcd = blockIdx.x & 7;
+    const int qq = blockIdx.x >> 3;
+    const int wt = qq % a.n_wt;
+    const int cg = a.cg0 + (qq / a.n_wt) * 8 + xcd;        // slot group
+    if (cg >= a.n_chgroups) return;
+    const int g = wt / a.P;
+    const int p = wt - g * a.P;
+    const int bps = a.nb * a.P;
+
+    const int s0 = (cg * W + wave) * CPW;                  // first slot of this wave (wave-uniform)
+    const int2 slot = pa.slots[min(s0 + csub, pa.n_slots - 1)];
+    const bool okA = s0 + csub < pa.n_slots && slot.x >= 0;     // (slot lists are padded with empty slots {-1, -1})
+    const bool okB = okA && slot.y >= 0;
+    const int chA = okA ? slot.x : 0, chB = okB ? slot.y : chA; // an empty place works on channel 0's table and stores nothing
+
+    const int slot0 = g * SPW * bps + a.nb * p;
+    if (slot0 * Y2B >= a.n_y2_new) return;
+
+    int tph = a.tphase0 + p * a.nb * SB;
+    tph %= a.N;
+    const float2 *xsrc = x_in + a.x_base + (size_t)slot0 * SB;
+    const int n_bodies = WU + a.nb;
+
+    // translator rows of this wave's slots: channel A's table (CONJ: the partner's is its conjugate), else A's and B's
+    int trowA[CPW], trowB[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+        trowA[c] = __builtin_amdgcn_readlane(chA, c * SPW);
+        trowB[c] = __builtin_amdgcn_readlane(chB, c * SPW);
+    }
+    auto issue_body = [&](int b, int bi, int tphb) {
+        char *buf = lds + bi * G::buf_bytes;
+        for (int r = wave; r < SPW; r += W)
+            dma_row<SB>(xsrc + (size_t)b * SB + (size_t)r * a.spacing, buf + r * G::row_bytes, lane);
+#pragma unroll
+        for (int c = 0; c < CPW; c++) {
+            dma_row<SB>(tables + (size_t)trowA[c] * a.tbl_stride + tphb, buf + (SPW + (wave * CPW + c) * TR) * G::row_bytes, lane);
+            if constexpr (!CONJ)
+                dma_row<SB>(tables + (size_t)trowB[c] * a.tbl_stride + tphb, buf + (SPW + (wave * CPW + c) * TR + 1) * G::row_bytes, lane);
+        }
+    };
+
+    v2f w1a[C1], w1b[C1], w2a[C2], w2b[C2];
+#pragma unroll
+    for (int i = 0; i < C1; i++) w1a[i] = w1b[i] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < C2; i++) w2a[i] = w2b[i] = v2f{0.f, 0.f};
+
+    const size_t yoff = a.y2_hist + ((size_t)wt * a.nb * SPW + sl) * Y2B;
+    float2 *__restrict__ ydA = y2_out + (size_t)chA * a.y2_stride + yoff;
+    float2 *__restrict__ ydB = y2_out + (size_t)chB * a.y2_stride + yoff;
+    v2f yA[Y2B], yB[Y2B];
+    auto store_y2 = [&](int body) {
+        static_assert(Y2B % 2 == 0, "16-byte stores");
+        if (okA) {
+            float2 *dst = ydA + (size_t)body * SPW * Y2B;
+#pragma unroll
+            for (int q = 0; q < Y2B; q += 2) *reinterpret_cast<v4f *>(dst + q) = v4f{yA[q].x, yA[q].y, yA[q + 1].x, yA[q + 1].y};
+        }
+        if (okB) {
+            float2 *dst = ydB + (size_t)body * SPW * Y2B;
+#pragma unroll
+            for (int q = 0; q < Y2B; q += 2) *reinterpret_cast<v4f *>(dst + q) = v4f{yB[q].x, yB[q].y, yB[q + 1].x, yB[q + 1].y};
+        }
+    };
+
+    issue_body(0, 0, tph);
+
+    for (int b = 0; b < n_bodies; b++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (b > WU) store_y2(b - 1 - WU);
+        tph += SB;
+        if (tph >= a.N) tph -= a.N;
+        if (b + 1 < n_bodies) issue_body(b + 1, (b + 1) & 1, tph);
+
+        const char *buf = lds + (b & 1) * G::buf_bytes;
+        const v4f *__restrict__ xrow = reinterpret_cast<const v4f *>(buf + sl * G::row_bytes);
+        const v4f *__restrict__ trA = reinterpret_cast<const v4f *>(buf + (SPW + (wave * CPW + csub) * TR) * G::row_bytes);
+        const v4f *__restrict__ trB = reinterpret_cast<const v4f *>(buf + (SPW + (wave * CPW + csub) * TR + (CONJ ? 0 : 1)) * G::row_bytes);
+
+        auto load_region = [&](const v4f *__restrict__ row, int k, v2f (&f)[M1], v2f &carry) {
+            const int idx0 = k * M1;
+            int first = idx0;
+            if (idx0 & 1) {
+                f[0] = carry;
+                first = idx0 + 1;
+            }
+#pragma unroll
+            for (int j = first; j < idx0 + M1; j += 2) {
+                const v4f v = row[j >> 1];
+                f[j - idx0] = v.xy;
+                if (j + 1 < idx0 + M1) f[j + 1 - idx0] = v.zw;
+                else carry = v.zw;
+            }
+        };
+
+        auto run_body = [&](auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            constexpr int KS = FIRST ? ((WU * NY1 - C2 > 0) ? ((WU * NY1 - C2 < NY1) ? WU * NY1 - C2 : NY1) : 0) : 0;
+            constexpr int KM = (KS * M1 - C1 > 0) ? (KS * M1 - C1) / M1 : 0;
+            v2f cx = {0.f, 0.f}, cta = {0.f, 0.f}, ctb = {0.f, 0.f};
+            v2f fx[2][M1];
+            v2f fta[M1], ftb[CONJ ? 1 : M1];
+            load_region(xrow, 0, fx[0], cx);
+            load_region(trA, 0, fta, cta);
+            if constexpr (!CONJ) load_region(trB, 0, ftb, ctb);
+#pragma unroll
+            for (int q = 0; q < Y2B; q++) {
+                v2f win2a[T2], win2b[T2];
+#pragma unroll
+                for (int i = 0; i < C2; i++) {
+                    win2a[i] = w2a[i];
+                    win2b[i] = w2b[i];
+                }
+#pragma unroll
+                for (int u = 0; u < M2; u++) {
+                    const int k = q * M2 + u;
+                    __builtin_amdgcn_sched_barrier(0);
+                    v2f wina[T1], winb[T1];
+#pragma unroll
+                    for (int i = 0; i < C1; i++) {
+                        wina[i] = w1a[i];
+                        winb[i] = w1b[i];
+                    }
+                    if (k >= KM) {
+                        if constexpr (CONJ) {
+                            cmul5_conj_pk(fx[k & 1], fta, &wina[C1], &winb[C1]);
+                        } else {
+                            cmul5_pk(fx[k & 1], fta, &wina[C1]);
+                            cmul5_pk(fx[k & 1], ftb, &winb[C1]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < M1; e++) {
+                            asm volatile("" : "+v"(wina[C1 + e]));
+                            asm volatile("" : "+v"(winb[C1 + e]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < M1; e++) wina[C1 + e] = winb[C1 + e] = v2f{0.f, 0.f};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 1 < NY1) {
+                        load_region(xrow, k + 1, fx[(k + 1) & 1], cx);
+                        load_region(trA, k + 1, fta, cta);
+                        if constexpr (!CONJ) load_region(trB, k + 1, ftb, ctb);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k >= KS) {
+                        win2a[C2 + u] = folded_fir_pk<T1>(wina, taps.h1);
+                        win2b[C2 + u] = folded_fir_pk<T1>(winb, taps.h1);
+                        asm volatile("" : "+v"(win2a[C2 + u]));
+                        asm volatile("" : "+v"(win2b[C2 + u]));
+                    } else {
+                        win2a[C2 + u] = win2b[C2 + u] = v2f{0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int i = 0; i < C1; i++) {
+                        w1a[i] = wina[i + M1];
+                        w1b[i] = winb[i + M1];
+                    }
+                }
+                if constexpr (!FIRST) {
+                    yA[q] = folded_fir_pk<T2>(win2a, taps.h2);
+                    yB[q] = folded_fir_pk<T2>(win2b, taps.h2);
+                    asm volatile("" : "+v"(yA[q]));
+                    asm volatile("" : "+v"(yB[q]));
+                }
+#pragma unroll
+                for (int i = 0; i < C2; i++) {
+                    w2a[i] = win2a[i + M2];
+                    w2b[i] = win2b[i + M2];
+                }
+            }
+        };
+        if (b == 0) run_body(std::true_type{});
+        else run_body(std::false_type{});
+    }
+    store_y2(a.nb - 1);
+
+    if constexpr (MA > 0) {
+        // stage 3 of the workgroup's own ranges, as in k_stage12; the workgroup's channels are its slots' A and B
+        static_assert(Y2B == 4, "fused stage 3: groups of 4 stage-2 outputs (two 16-byte pieces)");
+        const int seg_y2 = a.nb * Y2B;
+        const int rlen = SPW * seg_y2;
+        const int base = g * rlen;
+        const int end = min(base + rlen, a.n_y2_new);
+        const int rr_lo = (base + (TA - 1) - a.c0 + MA - 1) / MA;
+        const int rr_hi = (end - 1 - a.c0 >= 0) ? min((end - 1 - a.c0) / MA, a.n_y3 - 1) : -1;
+        const int n_int = rr_hi - rr_lo + 1;
+        const int npc = rlen / 2;
+        constexpr int NCH = 2 * W * CPW;                     // channel places of the workgroup
+        const int cpp = min(NCH, pa.lds_bytes / (rlen * 8));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const v2f *__restrict__ lds2 = reinterpret_cast<const v2f *>(lds);
+        const float rcp_seg = __builtin_amdgcn_rcpf((float)seg_y2);
+        auto source_offset = [&](int d0) -> uint32_t {
+            const int tt = 2 * min(d0 + lane, npc - 1);
+            const int seg = (int)(((float)tt + 0.5f) * rcp_seg);
+            const int rem = tt - seg * seg_y2;
+            return (uint32_t)((((rem / Y2B) * SPW + seg) * Y2B + (rem % Y2B)) * 8);
+        };
+        constexpr int NS = 8;
+        uint32_t soff[NS];
+#pragma unroll
+        for (int k = 0; k < NS; k++) soff[k] = source_offset(k * kWave);
+        const int n_third = (n_int + 2) / 3;
+        const float2 *__restrict__ ysrc = y2_out + a.y2_hist + base;
+        const int sbase = cg * W * CPW;                      // first slot of the workgroup
+        auto place_channel = [&](int i) -> int {             // place i = slot i/2, A or B; -1: empty
+            const int s = sbase + (i >> 1);
+            if (s >= pa.n_slots) return -1;
+            const int2 sp = pa.slots[s];
+            return (i & 1) ? sp.y : sp.x;
+        };
+        for (int cp0 = 0; cp0 < NCH; cp0 += cpp) {
+            const int ncp = min(cpp, NCH - cp0);
+            for (int ci = wave; ci < ncp; ci += W) {
+                const int chn = __builtin_amdgcn_readfirstlane(place_channel(cp0 + ci));
+                if (chn < 0) continue;
+                const char *grow = reinterpret_cast<const char *>(ysrc + (size_t)chn * a.y2_stride);
+                char *lrow = lds + (size_t)ci * rlen * 8;
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    if (k * kWave < npc && k * kWave + lane < npc)
+                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + soff[k]), (lds_void *)(uint32_t)(uintptr_t)(lrow + k * kWave * 16), 16, 0, 0);
+                }
+                for (int d0 = NS * kWave; d0 < npc; d0 += kWave) {
+                    if (d0 + lane < npc)
+                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + source_offset(d0)), (lds_void *)(uint32_t)(uintptr_t)(lrow + (size_t)d0 * 16), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int ci = wave; ci < ncp; ci += W) {
+                const int chn = __builtin_amdgcn_readfirstlane(place_channel(cp0 + ci));
+                if (chn < 0) continue;
+                const v2f *__restrict__ lrow = lds2 + ci * rlen;
+                constexpr int SE = 2 * (TA - 1);
+                static_assert(SE <= kWave, "seam entries of one range: one per lane");
+                if (lane < SE) seam_out[(size_t)chn * a.seam_stride + g * SE + lane] = *reinterpret_cast<const float2 *>(&lrow[lane < TA - 1 ? lane : rlen - SE + lane]);
+                float2 *__restrict__ y3row = y3_out + (size_t)chn * a.y3_stride + rr_lo;
+                const v2f *__restrict__ wrow = lrow + (MA * rr_lo + a.c0 - (TA - 1) - base);
+                for (int kp = lane; kp < n_third; kp += kWave) {
+                    const bool has1 = kp + n_third < n_int, has2 = kp + 2 * n_third < n_int;
+                    const int k1 = has1 ? kp + n_third : kp, k2 = has2 ? kp + 2 * n_third : kp;
+                    v2f r0 = {0.f, 0.f}, r1 = {0.f, 0.f}, r2 = {0.f, 0.f};
+                    folded_fir3_steps<TA>(r0, r1, r2, wrow + MA * kp, wrow + MA * k1, wrow + MA * k2, taps.h3);
+                    y3row[kp] = make_float2(r0.x, r0.y);
+                    if (has1) y3row[k1] = make_float2(r1.x, r1.y);
+                    if (has2) y3row[k2] = make_float2(r2.x, r2.y);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_tail: the remaining one or two decimator stages.  One workgroup per (channel, tile of
 // tile_b final outputs); the stage-2 outputs a tile needs (its own span plus the FIR history in
 // front of it) are staged in LDS, stage A is computed into LDS, stage B from there.  Tiles are

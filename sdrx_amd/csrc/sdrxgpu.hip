@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace sdrxgpu;
@@ -251,6 +252,46 @@ static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
+// two channels per lane (k_stage12p): compiled for the 10 MS/s chain, W = 4, CPW = 4
+struct K12PairLaunch {
+    K12Launch L;
+    PairArgs pa;
+    bool conj, fused;
+    size_t lds;
+};
+constexpr int kPairW = 4, kPairCPW = 4, kPairSlots = kPairW * kPairCPW;
+
+template <bool CONJ, int MA, int TA>
+static hipError_t launch_k12p_one(const K12PairLaunch &P, hipStream_t s)
+{
+    Stage12Taps<17, 19, TA> taps{};
+    for (int i = 0; i < 9; i++) taps.h1[i] = P.L.h1[i];
+    for (int i = 0; i < 10; i++) taps.h2[i] = P.L.h2[i];
+    if constexpr (MA > 0)
+        for (int i = 0; i < (TA + 1) / 2; i++) taps.h3[i] = P.L.h3[i];
+    hipLaunchKernelGGL((k_stage12p<17, 19, 4, kPairW, kPairCPW, CONJ, MA, TA>), dim3(P.L.grid), dim3(64 * kPairW), P.lds, s,
+                       P.L.x, P.L.tables, P.L.y2, P.L.y3, P.L.seam, P.L.args, P.pa, taps);
+    return hipGetLastError();
+}
+
+static hipError_t launch_k12p(const K12PairLaunch &P, hipStream_t s)
+{
+    if (P.fused) return P.conj ? launch_k12p_one<true, 5, 21>(P, s) : launch_k12p_one<false, 5, 21>(P, s);
+    return P.conj ? launch_k12p_one<true, 0, 1>(P, s) : launch_k12p_one<false, 0, 1>(P, s);
+}
+
+static size_t k12p_lds_bytes() { return 2 * (size_t)(kWave / kPairCPW + 2 * kPairSlots) * (100 * 8 + 16); }   // = the CONJ = false tiles
+
+static hipError_t k12p_set_attributes()
+{
+    const int n = (int)k12p_lds_bytes();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12p<17, 19, 4, kPairW, kPairCPW, true, 5, 21>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12p<17, 19, 4, kPairW, kPairCPW, false, 5, 21>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12p<17, 19, 4, kPairW, kPairCPW, true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12p<17, 19, 4, kPairW, kPairCPW, false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    return e;
+}
+
 struct K12Entry {
     int M1, T1, M2, T2, Y2B;
     int level;
@@ -372,6 +413,13 @@ struct sdrxgpu_bank {
 
     // host entries: copies on their own stream beside the kernels (sdrxgpu_bank_process: D2H of the first channel half
     // beside the kernels of the second; sdrxgpu_bank_process_pinned: H2D of block k+1 beside the kernels of block k)
+    // two channels per lane (k_stage12p): slot lists {channel A, channel B or -1; A = -1: empty}, ordered by host part,
+    // every part's share padded to whole workgroups of kPairSlots slots
+    bool pair = false;
+    int2 *d_slots_conj = nullptr, *d_slots_gen = nullptr;
+    int n_slots_conj = 0, n_slots_gen = 0, n_conj_pairs = 0;
+    std::vector<int> part_ch;                         // channel boundaries of the host parts: part p = [part_ch[p], part_ch[p+1])
+    std::vector<int> part_g_conj, part_g_gen;         // slot-group boundaries of the parts in the two lists
     hipStream_t copy_stream = nullptr;
     int host_parts = 0;                               // tuning.host_parts (0 = auto)
     hipEvent_t ev_part[8] = {};                       // kernels of a channel part are done
@@ -438,6 +486,8 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_hist2);
     (void)hipFree(b->d_hist3);
     (void)hipFree(b->d_seam);
+    (void)hipFree(b->d_slots_conj);
+    (void)hipFree(b->d_slots_gen);
     (void)hipFree(b->d_keep);
     (void)hipFree(b->d_audio_keep);
     (void)hipFree(b->d_state);
@@ -727,6 +777,92 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         }
     }
 
+    // Host parts (sdrxgpu_bank_process copies the rows of part p out while the kernels of part p+1 run): fixed here
+    // because the pairing below keeps partners inside one part.  Measured at 10 000 channels, page-locked buffers
+    // (ms per block): 1 part 2.26, 2: 1.85, 3: 1.73, 4: 1.68, 5: 1.69, 8: 1.79 (smaller parts fill the chip less well);
+    // automatic: about 2 500 channels per part, at most 4 parts.
+    {
+        const int gsz = b->W * b->CPW;
+        const int unit = gsz / (int)gcd_ll(gsz, kWave) * kWave;          // whole channel groups and whole k_agc blocks
+        int n_parts = 1;
+        if (!cfg->sql_level && !cfg->n_audio_fir_taps && !cfg->pan_pos && b->n_ch >= 2048)
+            n_parts = b->host_parts ? b->host_parts : std::min(4, std::max(1, (int)(b->n_ch / 2500)));
+        const int per = (((int)b->n_ch + n_parts - 1) / n_parts + unit - 1) / unit * unit;
+        b->part_ch.clear();
+        for (int c = 0; c < (int)b->n_ch; c += per) b->part_ch.push_back(c);
+        b->part_ch.push_back((int)b->n_ch);
+    }
+
+    // Two channels per lane (k_stage12p): for large banks of the 10 MS/s chain in its large-bank geometry.  Partners are
+    // looked for inside each host part: first channels whose tables are exact complex conjugates of each other
+    // (+k / -k steps from the tuner: they share the mixer), then whatever is left, two by two.
+    {
+        const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && b->W == kPairW &&
+                         b->CPW == kPairCPW && b->P == 1 && !b->pipelined && N > 0 &&
+                         (!b->fused || (k12->MA == 5 && k12->TA == 21));
+        if (tune.pair_lanes == 2 && !can) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.pair_lanes = 2, but this bank cannot run two channels per lane "
+                        "(10 MS/s chain, W = 4, CPW = 4, one body range per lane; W = %d, CPW = %d, P = %d)", b->W, b->CPW, b->P);
+        }
+        b->pair = can && (tune.pair_lanes == 2 || (tune.pair_lanes == 0 && b->n_ch >= 2048));
+    }
+    if (b->pair) {
+        std::vector<int2> conj, gen;
+        b->part_g_conj.assign(1, 0);
+        b->part_g_gen.assign(1, 0);
+        auto key_of = [&](uint32_t c, bool flip) {            // the table's bytes, imaginary parts negated when `flip`
+            const sdrxgpu_channel &ch = cfg->channels[c];
+            std::string k((const char *)ch.translator, (size_t)ch.n_translator * sizeof(sdrxgpu_iq));
+            if (flip)
+                for (size_t i = 0; i < ch.n_translator; i++) k[i * 8 + 7] ^= (char)0x80;   // sign bit of .im
+            return k;
+        };
+        for (size_t p = 0; p + 1 < b->part_ch.size(); p++) {
+            std::unordered_map<std::string, std::vector<int>> open;   // table bytes -> channels of this part still without partner
+            std::vector<int> single;
+            for (int c = b->part_ch[p]; c < b->part_ch[p + 1]; c++) {
+                if (cfg->channels[c].n_translator == 0) {
+                    single.push_back(c);
+                    continue;
+                }
+                auto it = open.find(key_of((uint32_t)c, true));
+                if (it != open.end() && !it->second.empty()) {
+                    conj.push_back(make_int2(it->second.back(), c));
+                    it->second.pop_back();
+                } else {
+                    open[key_of((uint32_t)c, false)].push_back(c);
+                }
+            }
+            for (auto &kv : open)
+                for (int c : kv.second) single.push_back(c);
+            std::sort(single.begin(), single.end());
+            for (size_t i = 0; i < single.size(); i += 2) gen.push_back(make_int2(single[i], i + 1 < single.size() ? single[i + 1] : -1));
+            while (conj.size() % kPairSlots) conj.push_back(make_int2(-1, -1));
+            while (gen.size() % kPairSlots) gen.push_back(make_int2(-1, -1));
+            b->part_g_conj.push_back((int)(conj.size() / kPairSlots));
+            b->part_g_gen.push_back((int)(gen.size() / kPairSlots));
+        }
+        b->n_conj_pairs = 0;
+        for (const int2 &sl : conj) b->n_conj_pairs += sl.x >= 0;
+        b->n_slots_conj = (int)conj.size();
+        b->n_slots_gen = (int)gen.size();
+        int rc2;
+        if ((rc2 = dev_alloc(b, (void **)&b->d_slots_conj, conj.size() * sizeof(int2))) ||
+            (rc2 = dev_alloc(b, (void **)&b->d_slots_gen, gen.size() * sizeof(int2)))) {
+            free_bank(b);
+            return rc2;
+        }
+        hipError_t e = hipSuccess;
+        if (!conj.empty()) e = hipMemcpy(b->d_slots_conj, conj.data(), conj.size() * sizeof(int2), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !gen.empty()) e = hipMemcpy(b->d_slots_gen, gen.data(), gen.size() * sizeof(int2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = k12p_set_attributes();
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "pair-lane set-up failed: %s", hipGetErrorString(e));
+        }
+    }
+
     if (cfg->stream) {
         b->stream = (hipStream_t)cfg->stream;
     } else {
@@ -979,7 +1115,7 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
     info->samples_out = b->n_out;
     info->device_bytes = b->device_bytes;
     info->fused_tail = b->fused ? 1u : 0u;
-    info->reserved = 0;
+    info->pair_lanes = b->pair ? (uint32_t)b->n_conj_pairs + 1u : 0u;
     return SDRXGPU_OK;
 }
 
@@ -1134,6 +1270,37 @@ static size_t outputs_of(const sdrxgpu_bank *b, uint64_t n0, size_t len)
 
 // Stage-1/2 of one chunk (<= max_chunk samples, already in the input ring) on stream `st`; fills `job` with
 // everything the tail launch needs except the output pointers and the history ping-pong side.
+static int launch_k12_range(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStream_t st, int cg_lo, int cg_hi);
+
+// Launch the stage-1/2 kernel of a prepared chunk for the host parts [p_lo, p_hi) (all of them: the whole bank).
+static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStream_t st, int p_lo, int p_hi)
+{
+    if (!b->pair) {
+        const int gsz = b->W * b->CPW;
+        return launch_k12_range(b, job, st, b->part_ch[p_lo] / gsz, (b->part_ch[p_hi] + gsz - 1) / gsz);
+    }
+    ProfScope ps(b, SDRXGPU_K_STAGE12, st);
+    for (int conj = 1; conj >= 0; conj--) {
+        const std::vector<int> &pg = conj ? b->part_g_conj : b->part_g_gen;
+        const int g_lo = pg[p_lo], g_hi = pg[p_hi];
+        if (g_hi <= g_lo) continue;
+        K12PairLaunch P;
+        P.L = job->L;
+        P.L.args.cg0 = g_lo;
+        P.L.args.n_chgroups = g_hi;
+        P.L.args.n_cgx = (g_hi - g_lo + 7) / 8 * 8;
+        P.L.grid = P.L.args.n_cgx * P.L.args.n_wt;
+        P.pa.slots = conj ? b->d_slots_conj : b->d_slots_gen;
+        P.pa.n_slots = conj ? b->n_slots_conj : b->n_slots_gen;
+        P.pa.lds_bytes = (int)k12p_lds_bytes();
+        P.lds = k12p_lds_bytes();
+        P.conj = conj != 0;
+        P.fused = b->fused;
+        HIPCHK(launch_k12p(P, st));
+    }
+    return SDRXGPU_OK;
+}
+
 // Launch the stage-1/2 kernel of a prepared chunk for the channel groups [cg_lo, cg_hi).
 static int launch_k12_range(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStream_t st, int cg_lo, int cg_hi)
 {
@@ -1226,7 +1393,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         }
         job->L = L;
         if (!defer) {
-            const int rc = launch_k12_range(b, job, st, 0, a.n_chgroups);
+            const int rc = launch_k12_parts(b, job, st, 0, (int)b->part_ch.size() - 1);
             if (rc) return rc;
         }
 
@@ -1555,8 +1722,6 @@ static int ensure_copy_stream(sdrxgpu_bank *b)
     return SDRXGPU_OK;
 }
 
-static int gcd_int(int a, int c) { return c ? gcd_int(c, a % c) : a; }
-
 // One chunk with HOST outputs.  The kernels write the compact keep buffers and the rows are copied out from there.  A
 // large plain bank runs as two channel halves: the rows of the first half cross PCIe on the copy stream while the
 // kernels of the second half run (61 MB of D2H per 10 000-channel block take as long as its kernels).
@@ -1568,20 +1733,14 @@ static int run_chunk_host(sdrxgpu_bank *b, size_t in_len, void *iq_out, void *au
     int rc = launch_stage12(b, in_len, b->stream, b->d_y2, &job, /*defer=*/true);
     if (rc || !job.valid) return rc;
     const int n_b = job.t.n_b;
-    const int gsz = b->W * b->CPW;
-    const int unit = gsz / gcd_int(gsz, kWave) * kWave;                 // whole channel groups and whole k_agc blocks
     const bool copies = n_b > 0 && (iq_out || audio_out);
-    int n_parts = 1;
-    // measured at 10 000 channels, page-locked buffers (ms per block): 1 part 2.26, 2: 1.85, 3: 1.73, 4: 1.68, 5: 1.69, 8: 1.79
-    // (smaller parts fill the chip less well); automatic: about 2 500 channels per part, at most 4 parts
-    if (copies && !b->squelch && !b->fir_T && !b->mix && b->n_ch >= 2048)
-        n_parts = b->host_parts ? b->host_parts : std::min(4, std::max(1, (int)(b->n_ch / 2500)));
-    const int per = (((int)b->n_ch + n_parts - 1) / n_parts + unit - 1) / unit * unit;   // channels per part
-    n_parts = ((int)b->n_ch + per - 1) / per;
+    const int n_all = (int)b->part_ch.size() - 1;
+    const int n_parts = copies ? n_all : 1;                  // (nothing to copy out: one launch over the whole bank)
     if (n_parts > 1 && (rc = ensure_copy_stream(b))) return rc;
     for (int p = 0; p < n_parts; p++) {
-        const int ch_lo = p * per, ch_hi = std::min((int)b->n_ch, ch_lo + per);
-        if ((rc = launch_k12_range(b, &job, b->stream, ch_lo / gsz, (ch_hi + gsz - 1) / gsz))) return rc;
+        const int p_lo = copies ? p : 0, p_hi = copies ? p + 1 : n_all;
+        const int ch_lo = b->part_ch[p_lo], ch_hi = b->part_ch[p_hi];
+        if ((rc = launch_k12_parts(b, &job, b->stream, p_lo, p_hi))) return rc;
         size_t prod = 0;
         if ((rc = launch_tail(b, &job, nullptr, nullptr, b->keep_stride, 0, &prod, ch_lo, ch_hi, p == n_parts - 1))) return rc;
         if (!copies) continue;

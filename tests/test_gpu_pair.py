@@ -1,0 +1,89 @@
+"""Two channels per lane in the stage-1/2 kernel (k_stage12p): conjugate partners (+k / -k steps from the tuner centre)
+share the input reads, the translator reads and half of the mixer; other channels are paired two by two and share the
+input reads.  Every channel's values come out of the same instruction sequence on the same operands as with one
+channel per lane, so the two kernels must agree bit for bit -- for every mix of partners, loners, untranslated
+channels, odd counts, both tail paths, ragged calls and the host entry's channel parts."""
+import numpy as np
+import pytest
+
+from conftest import RTOL, rel_err_rows
+from sdrx_amd import bank as sb, chains, synth
+
+pytestmark = pytest.mark.gpu
+
+WHOLE = 0xFFFFFFFF
+OFF, REQ = 1, 2
+
+
+def _run(ch, tabs, blocks, pair, fused, **kw):
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=WHOLE, tuning={"pair_lanes": pair, "fused_tail": fused, "k12_waves": 4, "k12_cpw": 4}, **kw)
+    info = bank.info()
+    outs = [bank.process(x) for x in blocks]
+    bank.close()
+    return np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1), info
+
+
+def _cut(stream, lens):
+    out, p = [], 0
+    for n in lens:
+        n = min(n, len(stream) - p)
+        out.append(stream[p:p + n])
+        p += n
+    assert p == len(stream)
+    return out
+
+
+@pytest.mark.parametrize("fused", [sb.FUSED_OFF, sb.FUSED_REQUIRE])
+@pytest.mark.parametrize("offs", [
+    list(range(-20, 21)),                                  # 20 conjugate pairs + the untranslated channel
+    [5, -5, 5, -5, 7, 9, 11, 0, 0, -7, 600 - 1200, 13],     # repeated offsets, loners, two untranslated, -600 (no partner)
+    [3],                                                   # a single channel
+    [4, -4],                                               # one pair
+    list(range(1, 38)),                                    # no partners at all: 37 loners -> 18 general pairs + 1
+])
+def test_pair_lanes_equal_single_lanes_bit_for_bit(offs, fused):
+    ch = chains.chain("10")
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    stream = synth.synth_iq(31, 0, 2 * L + 4321, 0.25, [t for t in tabs[:1] if t is not None], [0.3], ch.N, 10000)
+    lens = [L, 0, 624, 625, 777, L // 2, 10 ** 9]
+    want = _run(ch, tabs, _cut(stream, lens), OFF, fused)
+    got = _run(ch, tabs, _cut(stream, lens), REQ, fused)
+    assert want[2].pair_lanes == 0 and got[2].pair_lanes >= 1
+    assert np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32))
+    assert np.array_equal(want[1].view(np.uint32), got[1].view(np.uint32))
+
+
+def test_conjugate_pairs_are_found():
+    ch = chains.chain("10")
+    offs = list(range(-20, 21))
+    bank = sb.ChannelBank(sb.translators_for(ch, offs), ch.stage_tuples(), block_hint=WHOLE, tuning={"pair_lanes": REQ, "k12_waves": 4, "k12_cpw": 4})
+    assert bank.info().pair_lanes == 20 + 1                # 20 conjugate pairs (the count is reported + 1)
+    bank.close()
+
+
+def test_large_bank_pairs_by_default_and_matches_the_oracle_and_the_host_parts(oracle):
+    ch = chains.chain("10")
+    n_ch = 10000                                           # the bench workload: four host parts of 2 560 channels
+    offs = chains.offsets_cycled(n_ch, ch.N)
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    blocks = [synth.synth_iq(9, b * L, L, 0.25, [tabs[650]], [0.2], ch.N, 10000) for b in range(2)]
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    info = bank.info()
+    assert info.pair_lanes > 4000 and info.fused_tail == 1      # (partners are looked for inside a host part: 4 712 of the 4 990 possible)
+    outs = [bank.process(x) for x in blocks]                # host entry: channel parts, D2H beside the kernels
+    bank.close()
+    iq = np.concatenate([o[0] for o in outs], axis=1)
+    au = np.concatenate([o[1] for o in outs], axis=1)
+    single = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"pair_lanes": OFF})
+    assert single.info().pair_lanes == 0
+    o2 = [single.process(x) for x in blocks]
+    single.close()
+    assert np.array_equal(iq.view(np.uint32), np.concatenate([o[0] for o in o2], axis=1).view(np.uint32))
+    assert np.array_equal(au.view(np.uint32), np.concatenate([o[1] for o in o2], axis=1).view(np.uint32))
+    for c in (0, 1, 599, 600, 601, 1199, 1200, 2559, 2560, 9999):
+        ob = oracle.bank([tabs[c]], ch.stage_tuples())
+        r = [ob.process(x, threads=1) for x in blocks]
+        assert rel_err_rows(iq[c:c + 1], np.concatenate([v[0] for v in r], axis=1)) <= RTOL
+        assert rel_err_rows(au[c:c + 1], np.concatenate([v[1] for v in r], axis=1)) <= RTOL
