@@ -256,12 +256,12 @@ static hipError_t launch_k12(const K12Launch &L, hipStream_t s)
 struct K12PairLaunch {
     K12Launch L;
     PairArgs pa;
-    bool conj, fused;
+    bool fused;
     size_t lds;
 };
 constexpr int kPairW = 4, kPairCPW = 4, kPairSlots = kPairW * kPairCPW;
 
-template <bool CONJ, int MA, int TA>
+template <int MA, int TA>
 static hipError_t launch_k12p_one(const K12PairLaunch &P, hipStream_t s)
 {
     Stage12Taps<17, 19, TA> taps{};
@@ -269,26 +269,23 @@ static hipError_t launch_k12p_one(const K12PairLaunch &P, hipStream_t s)
     for (int i = 0; i < 10; i++) taps.h2[i] = P.L.h2[i];
     if constexpr (MA > 0)
         for (int i = 0; i < (TA + 1) / 2; i++) taps.h3[i] = P.L.h3[i];
-    hipLaunchKernelGGL((k_stage12p<17, 19, 4, kPairW, kPairCPW, CONJ, MA, TA>), dim3(P.L.grid), dim3(64 * kPairW), P.lds, s,
+    hipLaunchKernelGGL((k_stage12p<17, 19, 4, kPairW, kPairCPW, MA, TA>), dim3(P.L.grid), dim3(64 * kPairW), P.lds, s,
                        P.L.x, P.L.tables, P.L.y2, P.L.y3, P.L.seam, P.L.args, P.pa, taps);
     return hipGetLastError();
 }
 
 static hipError_t launch_k12p(const K12PairLaunch &P, hipStream_t s)
 {
-    if (P.fused) return P.conj ? launch_k12p_one<true, 5, 21>(P, s) : launch_k12p_one<false, 5, 21>(P, s);
-    return P.conj ? launch_k12p_one<true, 0, 1>(P, s) : launch_k12p_one<false, 0, 1>(P, s);
+    return P.fused ? launch_k12p_one<5, 21>(P, s) : launch_k12p_one<0, 1>(P, s);
 }
 
-static size_t k12p_lds_bytes() { return 2 * (size_t)(kWave / kPairCPW + 2 * kPairSlots) * (100 * 8 + 16); }   // = the CONJ = false tiles
+static size_t k12p_lds_bytes() { return 2 * (size_t)(kWave / kPairCPW + 2 * kPairSlots) * (100 * 8 + 16); }   // = the tiles of general groups
 
 static hipError_t k12p_set_attributes()
 {
     const int n = (int)k12p_lds_bytes();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12p<17, 19, 4, kPairW, kPairCPW, true, 5, 21>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12p<17, 19, 4, kPairW, kPairCPW, false, 5, 21>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12p<17, 19, 4, kPairW, kPairCPW, true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12p<17, 19, 4, kPairW, kPairCPW, false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12p<17, 19, 4, kPairW, kPairCPW, 5, 21>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12p<17, 19, 4, kPairW, kPairCPW, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
     return e;
 }
 
@@ -416,10 +413,11 @@ struct sdrxgpu_bank {
     // two channels per lane (k_stage12p): slot lists {channel A, channel B or -1; A = -1: empty}, ordered by host part,
     // every part's share padded to whole workgroups of kPairSlots slots
     bool pair = false;
-    int2 *d_slots_conj = nullptr, *d_slots_gen = nullptr;
-    int n_slots_conj = 0, n_slots_gen = 0, n_conj_pairs = 0;
+    int2 *d_slots = nullptr;
+    unsigned char *d_group_conj = nullptr;            // per slot group: conjugate partners (one translator row per slot) or any two channels
+    int n_slots = 0, n_conj_pairs = 0;
     std::vector<int> part_ch;                         // channel boundaries of the host parts: part p = [part_ch[p], part_ch[p+1])
-    std::vector<int> part_g_conj, part_g_gen;         // slot-group boundaries of the parts in the two lists
+    std::vector<int> part_g;                          // slot-group boundaries of the parts
     hipStream_t copy_stream = nullptr;
     int host_parts = 0;                               // tuning.host_parts (0 = auto)
     hipEvent_t ev_part[8] = {};                       // kernels of a channel part are done
@@ -486,8 +484,8 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_hist2);
     (void)hipFree(b->d_hist3);
     (void)hipFree(b->d_seam);
-    (void)hipFree(b->d_slots_conj);
-    (void)hipFree(b->d_slots_gen);
+    (void)hipFree(b->d_slots);
+    (void)hipFree(b->d_group_conj);
     (void)hipFree(b->d_keep);
     (void)hipFree(b->d_audio_keep);
     (void)hipFree(b->d_state);
@@ -808,9 +806,10 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         b->pair = can && (tune.pair_lanes == 2 || (tune.pair_lanes == 0 && b->n_ch >= 2048));
     }
     if (b->pair) {
-        std::vector<int2> conj, gen;
-        b->part_g_conj.assign(1, 0);
-        b->part_g_gen.assign(1, 0);
+        std::vector<int2> slots;
+        std::vector<unsigned char> group_conj;
+        b->part_g.assign(1, 0);
+        b->n_conj_pairs = 0;
         auto key_of = [&](uint32_t c, bool flip) {            // the table's bytes, imaginary parts negated when `flip`
             const sdrxgpu_channel &ch = cfg->channels[c];
             std::string k((const char *)ch.translator, (size_t)ch.n_translator * sizeof(sdrxgpu_iq));
@@ -820,6 +819,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         };
         for (size_t p = 0; p + 1 < b->part_ch.size(); p++) {
             std::unordered_map<std::string, std::vector<int>> open;   // table bytes -> channels of this part still without partner
+            std::vector<int2> conj, gen;
             std::vector<int> single;
             for (int c = b->part_ch[p]; c < b->part_ch[p + 1]; c++) {
                 if (cfg->channels[c].n_translator == 0) {
@@ -837,25 +837,29 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             for (auto &kv : open)
                 for (int c : kv.second) single.push_back(c);
             std::sort(single.begin(), single.end());
+            // conjugate pairs that do not fill a whole group go with the general ones (a conjugate pair is also just a pair)
+            while (conj.size() % kPairSlots) {
+                gen.push_back(conj.back());
+                conj.pop_back();
+            }
             for (size_t i = 0; i < single.size(); i += 2) gen.push_back(make_int2(single[i], i + 1 < single.size() ? single[i + 1] : -1));
-            while (conj.size() % kPairSlots) conj.push_back(make_int2(-1, -1));
             while (gen.size() % kPairSlots) gen.push_back(make_int2(-1, -1));
-            b->part_g_conj.push_back((int)(conj.size() / kPairSlots));
-            b->part_g_gen.push_back((int)(gen.size() / kPairSlots));
+            b->n_conj_pairs += (int)conj.size();
+            slots.insert(slots.end(), conj.begin(), conj.end());
+            group_conj.insert(group_conj.end(), conj.size() / kPairSlots, 1);
+            slots.insert(slots.end(), gen.begin(), gen.end());
+            group_conj.insert(group_conj.end(), gen.size() / kPairSlots, 0);
+            b->part_g.push_back((int)(slots.size() / kPairSlots));
         }
-        b->n_conj_pairs = 0;
-        for (const int2 &sl : conj) b->n_conj_pairs += sl.x >= 0;
-        b->n_slots_conj = (int)conj.size();
-        b->n_slots_gen = (int)gen.size();
+        b->n_slots = (int)slots.size();
         int rc2;
-        if ((rc2 = dev_alloc(b, (void **)&b->d_slots_conj, conj.size() * sizeof(int2))) ||
-            (rc2 = dev_alloc(b, (void **)&b->d_slots_gen, gen.size() * sizeof(int2)))) {
+        if ((rc2 = dev_alloc(b, (void **)&b->d_slots, slots.size() * sizeof(int2))) ||
+            (rc2 = dev_alloc(b, (void **)&b->d_group_conj, group_conj.size() + 16))) {
             free_bank(b);
             return rc2;
         }
-        hipError_t e = hipSuccess;
-        if (!conj.empty()) e = hipMemcpy(b->d_slots_conj, conj.data(), conj.size() * sizeof(int2), hipMemcpyHostToDevice);
-        if (e == hipSuccess && !gen.empty()) e = hipMemcpy(b->d_slots_gen, gen.data(), gen.size() * sizeof(int2), hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpy(b->d_slots, slots.data(), slots.size() * sizeof(int2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->d_group_conj, group_conj.data(), group_conj.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = k12p_set_attributes();
         if (e != hipSuccess) {
             free_bank(b);
@@ -1280,24 +1284,21 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
         return launch_k12_range(b, job, st, b->part_ch[p_lo] / gsz, (b->part_ch[p_hi] + gsz - 1) / gsz);
     }
     ProfScope ps(b, SDRXGPU_K_STAGE12, st);
-    for (int conj = 1; conj >= 0; conj--) {
-        const std::vector<int> &pg = conj ? b->part_g_conj : b->part_g_gen;
-        const int g_lo = pg[p_lo], g_hi = pg[p_hi];
-        if (g_hi <= g_lo) continue;
-        K12PairLaunch P;
-        P.L = job->L;
-        P.L.args.cg0 = g_lo;
-        P.L.args.n_chgroups = g_hi;
-        P.L.args.n_cgx = (g_hi - g_lo + 7) / 8 * 8;
-        P.L.grid = P.L.args.n_cgx * P.L.args.n_wt;
-        P.pa.slots = conj ? b->d_slots_conj : b->d_slots_gen;
-        P.pa.n_slots = conj ? b->n_slots_conj : b->n_slots_gen;
-        P.pa.lds_bytes = (int)k12p_lds_bytes();
-        P.lds = k12p_lds_bytes();
-        P.conj = conj != 0;
-        P.fused = b->fused;
-        HIPCHK(launch_k12p(P, st));
-    }
+    const int g_lo = b->part_g[p_lo], g_hi = b->part_g[p_hi];
+    if (g_hi <= g_lo) return SDRXGPU_OK;
+    K12PairLaunch P;
+    P.L = job->L;
+    P.L.args.cg0 = g_lo;
+    P.L.args.n_chgroups = g_hi;
+    P.L.args.n_cgx = (g_hi - g_lo + 7) / 8 * 8;
+    P.L.grid = P.L.args.n_cgx * P.L.args.n_wt;
+    P.pa.slots = b->d_slots;
+    P.pa.group_conj = b->d_group_conj;
+    P.pa.n_slots = b->n_slots;
+    P.pa.lds_bytes = (int)k12p_lds_bytes();
+    P.lds = k12p_lds_bytes();
+    P.fused = b->fused;
+    HIPCHK(launch_k12p(P, st));
     return SDRXGPU_OK;
 }
 
