@@ -109,7 +109,7 @@ def flops_per_channel_sample(chain, n_stages):
     return total
 
 
-def profile_facts(n_ch, fused):
+def profile_facts(n_ch, fused, pair):
     """HBM bytes per k_stage12 launch and the clock the chip sustains, from the rocprofv3 --pmc passes of this build
     (tools_pmc.sh -> profiles/*_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     None when no profile of this channel count / kernel path is committed."""
@@ -117,7 +117,7 @@ def profile_facts(n_ch, fused):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
-            if d.get("channels") == n_ch and bool(d.get("fused_tail", False)) == bool(fused):
+            if d.get("channels") == n_ch and bool(d.get("fused_tail", False)) == bool(fused) and bool(d.get("pair_lanes", False)) == bool(pair):
                 return d, os.path.basename(f)
         except (OSError, ValueError):
             pass
@@ -438,7 +438,7 @@ def main():
         f12 = flops_per_channel_sample(ch, 3 if fused else 2)     # what k_stage12 computes per channel-sample
         f_all = flops_per_channel_sample(ch, len(ch.stages))
         ach_tf = f12 * units / (k12_ms / 1e3) / 1e12 if k12_n else None
-        prof, prof_src = profile_facts(n_ch, fused)
+        prof, prof_src = profile_facts(n_ch, fused, pair_seen[n_ch])
         n_y2, n_y3 = L // (ch.stages[0].m * ch.stages[1].m), L // (ch.stages[0].m * ch.stages[1].m * ch.stages[2].m)
         if fused:     # k_tail4: [hist3 | y3] + the range-boundary buffer in, decimated IQ out twice (caller's buffer + the AGC's)
             tail_bytes = n_ch * (8.0 * (n_y3 + 80) + 8.0 * 40 * ((n_y2 + 767) // 768) + 2 * 8.0 * 512)

@@ -59,7 +59,9 @@ for k, d in agg.items():
 if "k_stage12" in out:
     out["k_stage12_hbm_bytes_per_launch"] = out["k_stage12"]["hbm_bytes_per_launch"]
     out["sustained_clock_ghz"] = out["k_stage12"].get("clock_ghz")
-if b3: out["fused_tail"] = "fused" in b3["config"]["kernel_path"].split("(")[0]
+if b3:
+    out["fused_tail"] = "fused" in b3["config"]["kernel_path"].split("(")[0]
+    out["pair_lanes"] = "two channels per lane" in b3["config"]["kernel_path"]
 json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
