@@ -89,3 +89,22 @@ def test_large_bank_pairs_by_default_and_matches_the_oracle_and_the_host_parts(o
         r = [ob.process(x, threads=1) for x in blocks]
         assert rel_err_rows(iq[c:c + 1], np.concatenate([v[0] for v in r], axis=1)) <= RTOL
         assert rel_err_rows(au[c:c + 1], np.concatenate([v[1] for v in r], axis=1)) <= RTOL
+
+
+def test_pair_lanes_with_ftfir_squelch_fm_and_audio_fir():
+    """Everything around the stage-1/2 kernel is unchanged by the lane layout: --ftfir (tables doubled and phase-shifted: still
+    conjugates of each other), squelch + FM + LF AGC + audio FIR downstream."""
+    ch = chains.chain("10")
+    offs = list(range(-12, 13)) + [300, -300, 7]
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    pb, ru, rd = chains.squelch_tables()
+    on = [False, True, True, False]
+    blocks = [synth.synth_iq(3, b * L, L, 0.25, [tabs[1]] if c else [], [0.25] if c else [], ch.N, 10000) for b, c in enumerate(on)]
+    kw = dict(ftfir=True, lf_agc=True, squelch=(np.full(len(offs), 6.0, np.float32), pb, ru, rd),
+              modulation=["FM" if i % 5 == 0 else "AM" for i in range(len(offs))], audio_fir=chains.audio_bpf_taps())
+    want = _run(ch, tabs, blocks, OFF, sb.FUSED_REQUIRE, **kw)
+    got = _run(ch, tabs, blocks, REQ, sb.FUSED_REQUIRE, **kw)
+    assert got[2].pair_lanes >= 1
+    assert np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32))
+    assert np.array_equal(want[1].view(np.uint32), got[1].view(np.uint32))
