@@ -412,7 +412,7 @@ struct sdrxgpu_bank {
     // beside the kernels of the second; sdrxgpu_bank_process_pinned: H2D of block k+1 beside the kernels of block k)
     // two channels per lane (k_stage12p): slot lists {channel A, channel B or -1; A = -1: empty}, ordered by host part,
     // every part's share padded to whole workgroups of kPairSlots slots
-    bool pair = false;
+    bool pair = false, want_pair = false;
     int2 *d_slots = nullptr;
     unsigned char *d_group_conj = nullptr;            // per slot group: conjugate partners (one translator row per slot) or any two channels
     int n_slots = 0, n_conj_pairs = 0;
@@ -735,6 +735,28 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: stage-1/2 geometry W=%d CPW=%d is not compiled for this chain or does not fit the LDS",
                         b->W, b->CPW);
         }
+        // Two channels per lane (k_stage12p) wanted?  Then the bodies per lane are chosen for ITS grid: workgroups of
+        // 32 channels, two per CU (same count of rounds x bodies model; measured at 1 024 / 2 048 / 4 096 channels: the
+        // choices below are the fastest or within 1 % of it).
+        b->want_pair = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && b->W == kPairW &&
+                       b->CPW == kPairCPW && !b->pipelined && N > 0 &&
+                       (tune.pair_lanes == 2 || (tune.pair_lanes == 0 && b->n_ch >= 1024));
+        if (b->want_pair) {
+            const int SPW = kWave / b->CPW;
+            const long long G = (U + (long long)SPW * b->bps - 1) / ((long long)SPW * b->bps);
+            const long long cgs = ((long long)b->n_ch + 2 * kPairSlots - 1) / (2 * kPairSlots);
+            const long long slots = 2LL * n_cu;
+            long long best_cost = -1;
+            for (int nb = b->bps; nb >= 1; nb--) {
+                if (b->bps % nb) continue;
+                const long long wgs = cgs * G * (b->bps / nb);
+                const long long cost = (wgs + slots - 1) / slots * (b->WU + nb);
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    b->nb = nb;
+                }
+            }
+        }
         if (cfg->block_hint == 0xFFFFFFFFu) {
             b->nb = b->bps;                   // whole segment per lane (P == 1)
         } else if (cfg->block_hint) {
@@ -796,14 +818,13 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     // (+k / -k steps from the tuner: they share the mixer), then whatever is left, two by two.
     {
         const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && b->W == kPairW &&
-                         b->CPW == kPairCPW && b->P == 1 && !b->pipelined && N > 0 &&
-                         (!b->fused || (k12->MA == 5 && k12->TA == 21));
+                         b->CPW == kPairCPW && !b->pipelined && N > 0 && (!b->fused || (k12->MA == 5 && k12->TA == 21));
         if (tune.pair_lanes == 2 && !can) {
             free_bank(b);
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.pair_lanes = 2, but this bank cannot run two channels per lane "
-                        "(10 MS/s chain, W = 4, CPW = 4, one body range per lane; W = %d, CPW = %d, P = %d)", b->W, b->CPW, b->P);
+                        "(10 MS/s chain, W = 4, CPW = 4; W = %d, CPW = %d)", b->W, b->CPW);
         }
-        b->pair = can && (tune.pair_lanes == 2 || (tune.pair_lanes == 0 && b->n_ch >= 2048));
+        b->pair = can && b->want_pair;
     }
     if (b->pair) {
         std::vector<int2> slots;

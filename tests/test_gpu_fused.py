@@ -87,15 +87,16 @@ def test_fused_split_invariance_and_reset():
         assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def test_large_bank_runs_fused_by_default_and_matches_the_oracle(oracle):
-    """4 000 channels of the 10 MS/s chain: the automatic geometry is W=4, CPW=4, a whole segment per lane -> fused."""
+def test_large_bank_automatic_path_matches_the_oracle(oracle):
+    """4 000 channels of the 10 MS/s chain, everything automatic (two channels per lane; whether stage 3 runs fused depends
+    on the bodies per lane the create call picks for this size -- tests/test_gpu_pair.py pins the 10 000-channel case)."""
     ch = chains.chain("10")
     offs = chains.offsets_cycled(4000, ch.N)
     tabs = sb.translators_for(ch, offs)
     L = ch.block_len
     blocks = [synth.synth_iq(77, b * L, L, 0.25, [tabs[700]], [0.2], ch.N, 10000) for b in range(2)]
     bank = sb.ChannelBank(tabs, ch.stage_tuples())
-    assert bank.info().fused_tail == 1
+    assert bank.info().pair_lanes > 1000
     iq, au = _run(bank, blocks)
     for c in (0, 1, 599, 600, 700, 1200, 3999):
         ob = oracle.bank([tabs[c]], ch.stage_tuples())
