@@ -312,6 +312,23 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): waits for n or fewer.
+__device__ __forceinline__ void wait_vmcnt_le(int n)
+{
+#define SDRX_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        SDRX_VMCNT_CASE(1) SDRX_VMCNT_CASE(2) SDRX_VMCNT_CASE(3) SDRX_VMCNT_CASE(4) SDRX_VMCNT_CASE(5) SDRX_VMCNT_CASE(6)
+        SDRX_VMCNT_CASE(7) SDRX_VMCNT_CASE(8) SDRX_VMCNT_CASE(9) SDRX_VMCNT_CASE(10) SDRX_VMCNT_CASE(11) SDRX_VMCNT_CASE(12)
+        SDRX_VMCNT_CASE(13) SDRX_VMCNT_CASE(14) SDRX_VMCNT_CASE(15) SDRX_VMCNT_CASE(16) SDRX_VMCNT_CASE(17) SDRX_VMCNT_CASE(18)
+        SDRX_VMCNT_CASE(19) SDRX_VMCNT_CASE(20) SDRX_VMCNT_CASE(21) SDRX_VMCNT_CASE(22) SDRX_VMCNT_CASE(23) SDRX_VMCNT_CASE(24)
+    default:
+        if (n >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (n > 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef SDRX_VMCNT_CASE
+}
+
 // One row of SB samples, global -> LDS, without touching VGPRs (global_load_lds_dwordx4):
 // lane i (< SB/2) moves 16 bytes from src + 2*i samples to dst + 16*i.
 template <int SB>
@@ -890,10 +907,8 @@ __device__ __forceinline__ void stage12p_body(const float2 *__restrict__ x_in, c
         const int n_int = rr_hi - rr_lo + 1;
         const int npc = rlen / 2;
         constexpr int NCH = 2 * W * CPW;                     // channel places of the workgroup
-        const int cpp = min(NCH, pa.lds_bytes / (rlen * 8));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const v2f *__restrict__ lds2 = reinterpret_cast<const v2f *>(lds);
         const float rcp_seg = __builtin_amdgcn_rcpf((float)seg_y2);
         auto source_offset = [&](int d0) -> uint32_t {
             const int tt = 2 * min(d0 + lane, npc - 1);
@@ -914,45 +929,60 @@ __device__ __forceinline__ void stage12p_body(const float2 *__restrict__ x_in, c
             const int2 sp = pa.slots[s];
             return (i & 1) ? sp.y : sp.x;
         };
-        for (int cp0 = 0; cp0 < NCH; cp0 += cpp) {
-            const int ncp = min(cpp, NCH - cp0);
-            for (int ci = wave; ci < ncp; ci += W) {
-                const int chn = __builtin_amdgcn_readfirstlane(place_channel(cp0 + ci));
-                if (chn < 0) continue;
-                const char *grow = reinterpret_cast<const char *>(ysrc + (size_t)chn * a.y2_stride);
-                char *lrow = lds + (size_t)ci * rlen * 8;
+        // Every wave works through its own places (wave, wave + W, ...) with its own LDS rows: the read-back of the
+        // next rows_w - 1 places is in flight while one place's outputs are computed, and no workgroup barrier is
+        // needed after the one above.  (DMA loads return in order: "at most k * ndma outstanding" = all older rows
+        // have landed, whatever the stores in between are doing.)
+        constexpr int NMY = NCH / W;
+        const int ndma = (npc + kWave - 1) / kWave;          // DMA instructions per row
+        const int rslot = ndma * kWave * 16;                 // bytes per row, whole instructions (the last one's spare lanes land in the pad)
+        const int rows_w = min(pa.lds_bytes / rslot / W, NMY);
+        char *const myrows = lds + (size_t)wave * rows_w * rslot;
+        const int chn0 = __builtin_amdgcn_readfirstlane(place_channel(0));
+        if (chn0 < 0 || rows_w < 1) return;
+        const int mych = place_channel(wave + min(lane, NMY - 1) * W);   // lane i: the wave's i-th channel (read once: a load here would drain the DMAs)
+        auto issue_row = [&](int i) {
+            int chn = __builtin_amdgcn_readlane(mych, i);
+            if (chn < 0) chn = chn0;                         // an empty place moves a row all the same (uniform counts) and computes nothing
+            const char *grow = reinterpret_cast<const char *>(ysrc + (size_t)chn * a.y2_stride);
+            char *lrow = myrows + (size_t)(i % rows_w) * rslot;
 #pragma unroll
-                for (int k = 0; k < NS; k++) {
-                    if (k * kWave < npc && k * kWave + lane < npc)
-                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + soff[k]), (lds_void *)(uint32_t)(uintptr_t)(lrow + k * kWave * 16), 16, 0, 0);
-                }
-                for (int d0 = NS * kWave; d0 < npc; d0 += kWave) {
-                    if (d0 + lane < npc)
-                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + source_offset(d0)), (lds_void *)(uint32_t)(uintptr_t)(lrow + (size_t)d0 * 16), 16, 0, 0);
-                }
+            for (int k = 0; k < NS; k++) {
+                if (k < ndma)
+                    __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + soff[k]), (lds_void *)(uint32_t)(uintptr_t)(lrow + k * kWave * 16), 16, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            for (int ci = wave; ci < ncp; ci += W) {
-                const int chn = __builtin_amdgcn_readfirstlane(place_channel(cp0 + ci));
-                if (chn < 0) continue;
-                const v2f *__restrict__ lrow = lds2 + ci * rlen;
+            for (int k = NS; k < ndma; k++)
+                __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + source_offset(k * kWave)), (lds_void *)(uint32_t)(uintptr_t)(lrow + (size_t)k * kWave * 16), 16, 0, 0);
+        };
+        for (int i = 0; i < rows_w; i++) issue_row(i);
+        for (int i = 0; i < NMY; i++) {
+            wait_vmcnt_le(min(rows_w - 1, NMY - 1 - i) * ndma);
+            const int chn = __builtin_amdgcn_readlane(mych, i);
+            if (chn >= 0) {
+                const v2f *__restrict__ lrow = reinterpret_cast<const v2f *>(myrows + (size_t)(i % rows_w) * rslot);
                 constexpr int SE = 2 * (TA - 1);
                 static_assert(SE <= kWave, "seam entries of one range: one per lane");
                 if (lane < SE) seam_out[(size_t)chn * a.seam_stride + g * SE + lane] = *reinterpret_cast<const float2 *>(&lrow[lane < TA - 1 ? lane : rlen - SE + lane]);
                 float2 *__restrict__ y3row = y3_out + (size_t)chn * a.y3_stride + rr_lo;
                 const v2f *__restrict__ wrow = lrow + (MA * rr_lo + a.c0 - (TA - 1) - base);
                 for (int kp = lane; kp < n_third; kp += kWave) {
-                    const bool has1 = kp + n_third < n_int, has2 = kp + 2 * n_third < n_int;
-                    const int k1 = has1 ? kp + n_third : kp, k2 = has2 ? kp + 2 * n_third : kp;
+                    // three neighbouring outputs per lane: their windows overlap, TA + 2 MA samples are read once
+                    const int r = 3 * kp;
+                    v2f win[TA + 2 * MA];
+#pragma unroll
+                    for (int j = 0; j < TA + 2 * MA; j++) win[j] = wrow[MA * r + j];
                     v2f r0 = {0.f, 0.f}, r1 = {0.f, 0.f}, r2 = {0.f, 0.f};
-                    folded_fir3_steps<TA>(r0, r1, r2, wrow + MA * kp, wrow + MA * k1, wrow + MA * k2, taps.h3);
-                    y3row[kp] = make_float2(r0.x, r0.y);
-                    if (has1) y3row[k1] = make_float2(r1.x, r1.y);
-                    if (has2) y3row[k2] = make_float2(r2.x, r2.y);
+                    folded_fir3_steps<TA>(r0, r1, r2, win, win + MA, win + 2 * MA, taps.h3);
+                    y3row[r] = make_float2(r0.x, r0.y);
+                    if (r + 1 < n_int) y3row[r + 1] = make_float2(r1.x, r1.y);
+                    if (r + 2 < n_int) y3row[r + 2] = make_float2(r2.x, r2.y);
                 }
             }
-            __syncthreads();
+            if (i + rows_w < NMY) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row's reads are done before it is filled again
+                __builtin_amdgcn_sched_barrier(0);
+                issue_row(i + rows_w);
+            }
         }
     }
 }

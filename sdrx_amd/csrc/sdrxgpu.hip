@@ -817,8 +817,11 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     // looked for inside each host part: first channels whose tables are exact complex conjugates of each other
     // (+k / -k steps from the tuner: they share the mixer), then whatever is left, two by two.
     {
+        // (fused: every wave of a workgroup reads its channels' ranges back into LDS rows of its own, one at least)
+        const size_t epilogue_row = ((size_t)(kWave / b->CPW) * b->bps * k12->Y2B / 2 + kWave - 1) / kWave * kWave * 16;
         const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && b->W == kPairW &&
-                         b->CPW == kPairCPW && !b->pipelined && N > 0 && (!b->fused || (k12->MA == 5 && k12->TA == 21));
+                         b->CPW == kPairCPW && !b->pipelined && N > 0 &&
+                         (!b->fused || (k12->MA == 5 && k12->TA == 21 && k12p_lds_bytes() / epilogue_row >= (size_t)kPairW));
         if (tune.pair_lanes == 2 && !can) {
             free_bank(b);
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.pair_lanes = 2, but this bank cannot run two channels per lane "
@@ -1773,14 +1776,16 @@ static int run_chunk_host(sdrxgpu_bank *b, size_t in_len, void *iq_out, void *au
             cs = b->copy_stream;
         }
         const size_t rows = (size_t)(ch_hi - ch_lo);
-        if (iq_out)
-            HIPCHK(hipMemcpy2DAsync((float2 *)iq_out + (size_t)ch_lo * out_stride + out_off, out_stride * sizeof(float2),
-                                    b->d_keep + (size_t)ch_lo * b->keep_stride, (size_t)b->keep_stride * sizeof(float2),
-                                    (size_t)n_b * sizeof(float2), rows, hipMemcpyDeviceToHost, cs));
-        if (audio_out)
-            HIPCHK(hipMemcpy2DAsync((float *)audio_out + (size_t)ch_lo * out_stride + out_off, out_stride * sizeof(float),
-                                    b->d_audio_keep + (size_t)ch_lo * b->keep_stride, (size_t)b->keep_stride * sizeof(float),
-                                    (size_t)n_b * sizeof(float), rows, hipMemcpyDeviceToHost, cs));
+        // (rows that touch on both sides -- whole blocks into a [n_channels][512] array -- go as ONE linear copy)
+        auto rows_out = [&](void *dst, const void *src, size_t elem) -> hipError_t {
+            char *d = (char *)dst + ((size_t)ch_lo * out_stride + out_off) * elem;
+            const char *s_ = (const char *)src + (size_t)ch_lo * b->keep_stride * elem;
+            if (out_stride == (size_t)n_b && b->keep_stride == n_b)
+                return hipMemcpyAsync(d, s_, rows * n_b * elem, hipMemcpyDeviceToHost, cs);
+            return hipMemcpy2DAsync(d, out_stride * elem, s_, (size_t)b->keep_stride * elem, (size_t)n_b * elem, rows, hipMemcpyDeviceToHost, cs);
+        };
+        if (iq_out) HIPCHK(rows_out(iq_out, b->d_keep, sizeof(float2)));
+        if (audio_out) HIPCHK(rows_out(audio_out, b->d_audio_keep, sizeof(float)));
     }
     if (n_parts > 1) {      // the keep buffers are free again (next chunk, next call) once the copies have read them
         HIPCHK(hipEventRecord(b->ev_d2h, b->copy_stream));
