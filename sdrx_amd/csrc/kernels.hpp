@@ -941,25 +941,31 @@ __device__ __forceinline__ void stage12p_body(const float2 *__restrict__ x_in, c
         const int chn0 = __builtin_amdgcn_readfirstlane(place_channel(0));
         if (chn0 < 0 || rows_w < 1) return;
         const int mych = place_channel(wave + min(lane, NMY - 1) * W);   // lane i: the wave's i-th channel (read once: a load here would drain the DMAs)
-        auto issue_row = [&](int i) {
-            int chn = __builtin_amdgcn_readlane(mych, i);
-            if (chn < 0) chn = chn0;                         // an empty place moves a row all the same (uniform counts) and computes nothing
-            const char *grow = reinterpret_cast<const char *>(ysrc + (size_t)chn * a.y2_stride);
-            char *lrow = myrows + (size_t)(i % rows_w) * rslot;
+        // (ndma_tag, rows_tag) = compile-time (ndma, rows_w), or (0, 0): the run-time values.  With constants the loop over
+        // the wave's places unrolls and every wait is an immediate.
+        auto rows_pipeline = [&](auto ndma_tag, auto rows_tag) {
+            constexpr bool CT = decltype(ndma_tag)::value > 0;
+            const int nd = CT ? decltype(ndma_tag)::value : ndma;
+            const int rw = CT ? decltype(rows_tag)::value : rows_w;
+            auto issue_row = [&](int i) {
+                int chn = __builtin_amdgcn_readlane(mych, i);
+                if (chn < 0) chn = chn0;                     // an empty place moves a row all the same (uniform counts) and computes nothing
+                const char *grow = reinterpret_cast<const char *>(ysrc + (size_t)chn * a.y2_stride);
+                char *lrow = myrows + (size_t)(i % rw) * rslot;
 #pragma unroll
-            for (int k = 0; k < NS; k++) {
-                if (k < ndma)
-                    __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + soff[k]), (lds_void *)(uint32_t)(uintptr_t)(lrow + k * kWave * 16), 16, 0, 0);
-            }
-            for (int k = NS; k < ndma; k++)
-                __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + source_offset(k * kWave)), (lds_void *)(uint32_t)(uintptr_t)(lrow + (size_t)k * kWave * 16), 16, 0, 0);
-        };
-        for (int i = 0; i < rows_w; i++) issue_row(i);
-        for (int i = 0; i < NMY; i++) {
-            wait_vmcnt_le(min(rows_w - 1, NMY - 1 - i) * ndma);
-            const int chn = __builtin_amdgcn_readlane(mych, i);
-            if (chn >= 0) {
-                const v2f *__restrict__ lrow = reinterpret_cast<const v2f *>(myrows + (size_t)(i % rows_w) * rslot);
+                for (int k = 0; k < NS; k++) {
+                    if (k < nd)
+                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + soff[k]), (lds_void *)(uint32_t)(uintptr_t)(lrow + k * kWave * 16), 16, 0, 0);
+                }
+                if constexpr (!CT || decltype(ndma_tag)::value > NS) {
+                    for (int k = NS; k < nd; k++)
+                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + source_offset(k * kWave)), (lds_void *)(uint32_t)(uintptr_t)(lrow + (size_t)k * kWave * 16), 16, 0, 0);
+                }
+            };
+            auto row_outputs = [&](int i) {
+                const int chn = __builtin_amdgcn_readlane(mych, i);
+                if (chn < 0) return;
+                const v2f *__restrict__ lrow = reinterpret_cast<const v2f *>(myrows + (size_t)(i % rw) * rslot);
                 constexpr int SE = 2 * (TA - 1);
                 static_assert(SE <= kWave, "seam entries of one range: one per lane");
                 if (lane < SE) seam_out[(size_t)chn * a.seam_stride + g * SE + lane] = *reinterpret_cast<const float2 *>(&lrow[lane < TA - 1 ? lane : rlen - SE + lane]);
@@ -977,13 +983,30 @@ __device__ __forceinline__ void stage12p_body(const float2 *__restrict__ x_in, c
                     if (r + 1 < n_int) y3row[r + 1] = make_float2(r1.x, r1.y);
                     if (r + 2 < n_int) y3row[r + 2] = make_float2(r2.x, r2.y);
                 }
+            };
+            auto step = [&](int i) {
+                wait_vmcnt_le(min(rw - 1, NMY - 1 - i) * nd);
+                row_outputs(i);
+                if (i + rw < NMY) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row's reads are done before it is filled again
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_row(i + rw);
+                }
+            };
+            if constexpr (CT) {
+#pragma unroll
+                for (int i = 0; i < decltype(rows_tag)::value; i++) issue_row(i);
+#pragma unroll
+                for (int i = 0; i < NMY; i++) step(i);
+            } else {
+                for (int i = 0; i < rw; i++) issue_row(i);
+                for (int i = 0; i < NMY; i++) step(i);
             }
-            if (i + rows_w < NMY) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row's reads are done before it is filled again
-                __builtin_amdgcn_sched_barrier(0);
-                issue_row(i + rows_w);
-            }
-        }
+        };
+        if (ndma == 6 && rows_w == 3)        // N = 1200: ranges of 768 outputs, 6 KB per row
+            rows_pipeline(std::integral_constant<int, 6>{}, std::integral_constant<int, 3>{});
+        else
+            rows_pipeline(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     }
 }
 
