@@ -1047,7 +1047,7 @@ struct TailArgs {
     const float2 *hist_in;  // [n_ch][hist]
     float2       *hist_out; // [n_ch][hist]
     float2       *iq_out;   // [n_ch][out_stride] or nullptr
-    float2       *iq_keep;  // [n_ch][keep_stride] compact copy for k_agc (never null)
+    float2       *iq_keep;  // [n_ch][keep_stride] compact copy for k_agc / k_squelch, or nullptr: they read iq_out
     int n_ch;               // one past the last channel of this launch
     int ch_lo;              // its first channel (a launch may cover part of the bank)
     int y2_stride, hist, n_y2_new;
@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(256) void k_tail(const TailArgs a)
         if (s < nbt && hsel == 0) {
             const float2 o = make_float2(acc.x, acc.y);
             if (a.iq_out) a.iq_out[(size_t)ch * a.out_stride + s0 + s] = o;
-            a.iq_keep[(size_t)ch * a.keep_stride + s0 + s] = o;
+            if (a.iq_keep) a.iq_keep[(size_t)ch * a.keep_stride + s0 + s] = o;
         }
     }
 }
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
         const v2f r = folded_fir_unrolled<TB>(bsrc + MB * tid, a.hB);
         const float2 o = make_float2(r.x, r.y);
         if (a.iq_out) a.iq_out[(size_t)ch * a.out_stride + s0 + tid] = o;
-        a.iq_keep[(size_t)ch * a.keep_stride + s0 + tid] = o;
+        if (a.iq_keep) a.iq_keep[(size_t)ch * a.keep_stride + s0 + tid] = o;
     }
 }
 
@@ -1418,8 +1418,10 @@ __global__ __launch_bounds__(256) void k_tail4(const Tail4Args a)
             t.iq_out[(size_t)ch * t.out_stride + k] = o0;
             if (second) t.iq_out[(size_t)ch * t.out_stride + k2] = o1;
         }
-        t.iq_keep[(size_t)ch * t.keep_stride + k] = o0;
-        if (second) t.iq_keep[(size_t)ch * t.keep_stride + k2] = o1;
+        if (t.iq_keep) {
+            t.iq_keep[(size_t)ch * t.keep_stride + k] = o0;
+            if (second) t.iq_keep[(size_t)ch * t.keep_stride + k2] = o1;
+        }
     }
     // (5) histories for the next call (every read of the old ones is behind the barriers above)
     for (int i = tid; i < a.H3; i += 256) {

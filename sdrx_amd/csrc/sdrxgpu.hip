@@ -1523,6 +1523,12 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     t.ch_lo = ch_lo;
     t.iq_out = d_iq_out ? d_iq_out + out_off : nullptr;
     t.out_stride = (int)out_stride;
+    // k_agc / k_squelch read the decimated IQ rows 16 bytes at a time: from the caller's rows when those are aligned
+    // (then no second copy is written), else from the compact keep buffer
+    const bool iq_direct = t.iq_out && out_stride % 2 == 0 && ((uintptr_t)t.iq_out & 15) == 0;
+    t.iq_keep = iq_direct ? nullptr : b->d_keep;
+    const float2 *iq_rows = iq_direct ? t.iq_out : b->d_keep;
+    const int iq_rows_stride = iq_direct ? (int)out_stride : b->keep_stride;
     if (b->fused) {
         // boundary stage-3 outputs + last stage, one workgroup per channel (k_tail4)
         Tail4Args f;
@@ -1575,8 +1581,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     // ---- AGC -> |.| -> LF AGC ----
     if (t.n_b > 0) {
         AgcArgs g;
-        g.iq = b->d_keep;
-        g.iq_stride = b->keep_stride;
+        g.iq = iq_rows;
+        g.iq_stride = iq_rows_stride;
         g.audio = d_audio_out ? d_audio_out + out_off : b->d_audio_keep;
         g.out_stride = d_audio_out ? (int)out_stride : b->keep_stride;
         g.state = b->d_state;
@@ -1619,8 +1625,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         // (banks with squelch, audio FIR or mix-down are never run in parts: these work on the whole bank)
         if (b->squelch) {
             SquelchArgs q;
-            q.iq = b->d_keep;
-            q.iq_stride = b->keep_stride;
+            q.iq = iq_rows;
+            q.iq_stride = iq_rows_stride;
             q.window = b->d_sq_tabs;
             q.pb = b->d_sq_tabs + 512;
             q.tw = b->d_tw;
