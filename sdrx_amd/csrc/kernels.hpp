@@ -349,15 +349,149 @@ __device__ __forceinline__ void dma_row(const float2 *src_row /* wave-uniform */
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Stage 3 of a workgroup's OWN ranges, behind the stage-1/2 main loop (k_stage12<.., MA, TA> / k_stage12p<.., MA, TA>).
+// With one body range per lane (P == 1) the workgroup has just written, for each of its channels, one contiguous range
+// of RLEN = SPW * nb * Y2B stage-2 outputs.  Every stage-3 output whose window lies inside that range ("interior":
+// all but the ~(TA-1)/MA outputs at each range boundary) is computed here and goes to y3_out[ch][rr]; the first and the
+// last TA-1 outputs of the range go compactly to seam_out for k_tail4, which computes the boundary outputs with the
+// same instruction sequence and runs the last stage.
+//
+// Every wave (of the first `wa`: as many as the LDS has rows for, stage3_split) works through its own n_my channels with
+// LDS rows of its own (the tiles' LDS, free now): a row = one
+// channel's range, fetched back by LDS-DMA with permuted source addresses so that it lands in TIME order; the
+// read-back of the next rows is in flight while one row's outputs are computed, and there is no barrier after the one
+// at the top (the range was written by this workgroup's waves: s_waitcnt vmcnt(0) + barrier is all the ordering
+// needed).  DMA loads return in order, so "at most k * ndma loads outstanding" means every older row has landed,
+// whatever the stores in between are doing.  A lane computes three neighbouring outputs from the TA + 2 MA samples
+// their windows span (fma_tap3: three alternating accumulation chains; per output the same instruction sequence on
+// the same operands as anywhere else).
+//   mych: lane i (< n_my) holds the wave's i-th channel (place wave + i * wa of the workgroup's), or -1 (no channel: a
+//         row is moved all the same, so that the counts stay uniform, from chn0 -- any valid channel of the workgroup --
+//         and nothing is computed)
+//   NMY:  n_my when all W waves take part (the compile-time variant of the loop)
+// ------------------------------------------------------------------------------------------
+// how the workgroup's n_places channels are dealt to its waves: the first wa waves, n_my channels each
+template <int SPW, int Y2B, int W>
+__device__ __forceinline__ void stage3_split(const Stage12Args &a, const int n_places, const int lds_bytes, int &wa, int &n_my)
+{
+    const int ndma = (SPW * a.nb * Y2B / 2 + kWave - 1) / kWave;
+    wa = max(1, min(W, lds_bytes / (ndma * kWave * 16)));    // (host: the LDS holds one row at least)
+    n_my = (n_places + wa - 1) / wa;
+}
+
+template <int MA, int TA, int SPW, int Y2B, int W, int NMY, int NH3>
+__device__ __forceinline__ void stage3_epilogue(const Stage12Args &a, const float (&h3)[NH3], const float2 *__restrict__ y2_out,
+                                                float2 *__restrict__ y3_out, float2 *__restrict__ seam_out, char *lds, const int lds_bytes,
+                                                const int g, const int wave, const int lane, const int wa, const int n_my,
+                                                const int mych, const int chn0)
+{
+    static_assert(Y2B == 4, "fused stage 3: groups of 4 stage-2 outputs (two 16-byte pieces)");
+    const int seg_y2 = a.nb * Y2B;                           // stage-2 outputs per segment (P == 1: nb = bodies per segment)
+    const int rlen = SPW * seg_y2;                           // ... per workgroup range
+    const int base = g * rlen;                               // first stage-2 output (index within the call) of this range
+    const int end = min(base + rlen, a.n_y2_new);
+    // interior outputs rr_lo .. rr_hi: window [MA*rr + c0 - (TA-1), MA*rr + c0] inside [base, end)
+    const int rr_lo = (base + (TA - 1) - a.c0 + MA - 1) / MA;
+    const int rr_hi = (end - 1 - a.c0 >= 0) ? min((end - 1 - a.c0) / MA, a.n_y3 - 1) : -1;
+    const int n_int = rr_hi - rr_lo + 1;
+    const int npc = rlen / 2;                                // 16-byte pieces of one channel's range
+    // every store of this workgroup's range has left its wave, and every wave is done with the tiles
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float rcp_seg = __builtin_amdgcn_rcpf((float)seg_y2);
+    auto source_offset = [&](int d0) -> uint32_t {           // LDS piece d0 + lane (samples 2d, 2d+1 in time order) <- where the main loop stored it
+        const int tt = 2 * min(d0 + lane, npc - 1);
+        const int seg = (int)(((float)tt + 0.5f) * rcp_seg);
+        const int rem = tt - seg * seg_y2;
+        return (uint32_t)((((rem / Y2B) * SPW + seg) * Y2B + (rem % Y2B)) * 8);
+    };
+    constexpr int NS = 8;
+    uint32_t soff[NS];                                       // (what does not depend on the channel is computed once)
+#pragma unroll
+    for (int k = 0; k < NS; k++) soff[k] = source_offset(k * kWave);
+    const int n_third = (n_int + 2) / 3;
+    const float2 *__restrict__ ysrc = y2_out + a.y2_hist + base;
+    const int ndma = (npc + kWave - 1) / kWave;              // DMA instructions per row
+    const int rslot = ndma * kWave * 16;                     // bytes per row, whole instructions (the last one's spare lanes land in the pad)
+    const int rows_w = min(lds_bytes / rslot / wa, n_my);    // (>= 1: stage3_split)
+    char *const myrows = lds + (size_t)wave * rows_w * rslot;
+    if (chn0 < 0 || rows_w < 1 || wave >= wa) return;
+    // (ndma_tag, rows_tag) = compile-time (ndma, rows_w), or (0, 0): the run-time values.  With constants the loop over
+    // the wave's channels unrolls and every wait is an immediate.
+    auto rows_pipeline = [&](auto ndma_tag, auto rows_tag) {
+        constexpr bool CT = decltype(ndma_tag)::value > 0;
+        const int nd = CT ? decltype(ndma_tag)::value : ndma;
+        const int rw = CT ? decltype(rows_tag)::value : rows_w;
+        auto issue_row = [&](int i) {
+            int chn = __builtin_amdgcn_readlane(mych, i);
+            if (chn < 0) chn = chn0;
+            const char *grow = reinterpret_cast<const char *>(ysrc + (size_t)chn * a.y2_stride);
+            char *lrow = myrows + (size_t)(i % rw) * rslot;
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                if (k < nd)
+                    __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + soff[k]), (lds_void *)(uint32_t)(uintptr_t)(lrow + k * kWave * 16), 16, 0, 0);
+            }
+            if constexpr (!CT || decltype(ndma_tag)::value > NS) {
+                for (int k = NS; k < nd; k++)
+                    __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + source_offset(k * kWave)), (lds_void *)(uint32_t)(uintptr_t)(lrow + (size_t)k * kWave * 16), 16, 0, 0);
+            }
+        };
+        auto row_outputs = [&](int i) {
+            const int chn = __builtin_amdgcn_readlane(mych, i);
+            if (chn < 0) return;
+            const v2f *__restrict__ lrow = reinterpret_cast<const v2f *>(myrows + (size_t)(i % rw) * rslot);
+            constexpr int SE = 2 * (TA - 1);
+            static_assert(SE <= kWave, "seam entries of one range: one per lane");
+            if (lane < SE) seam_out[(size_t)chn * a.seam_stride + g * SE + lane] = *reinterpret_cast<const float2 *>(&lrow[lane < TA - 1 ? lane : rlen - SE + lane]);
+            float2 *__restrict__ y3row = y3_out + (size_t)chn * a.y3_stride + rr_lo;
+            const v2f *__restrict__ wrow = lrow + (MA * rr_lo + a.c0 - (TA - 1) - base);
+            for (int kp = lane; kp < n_third; kp += kWave) {
+                const int r = 3 * kp;
+                v2f win[TA + 2 * MA];
+#pragma unroll
+                for (int j = 0; j < TA + 2 * MA; j++) win[j] = wrow[MA * r + j];
+                v2f r0 = {0.f, 0.f}, r1 = {0.f, 0.f}, r2 = {0.f, 0.f};
+                folded_fir3_steps<TA>(r0, r1, r2, win, win + MA, win + 2 * MA, h3);
+                y3row[r] = make_float2(r0.x, r0.y);
+                if (r + 1 < n_int) y3row[r + 1] = make_float2(r1.x, r1.y);
+                if (r + 2 < n_int) y3row[r + 2] = make_float2(r2.x, r2.y);
+            }
+        };
+        const int nm = CT ? NMY : n_my;
+        auto step = [&](int i) {
+            wait_vmcnt_le(min(rw - 1, nm - 1 - i) * nd);
+            row_outputs(i);
+            if (i + rw < nm) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row's reads are done before it is filled again
+                __builtin_amdgcn_sched_barrier(0);
+                issue_row(i + rw);
+            }
+        };
+        if constexpr (CT) {
+#pragma unroll
+            for (int i = 0; i < decltype(rows_tag)::value; i++) issue_row(i);
+#pragma unroll
+            for (int i = 0; i < NMY; i++) step(i);
+        } else {
+            for (int i = 0; i < rw; i++) issue_row(i);
+            for (int i = 0; i < nm; i++) step(i);
+        }
+    };
+    if constexpr (NMY >= 8) {
+        if (ndma == 6 && rows_w == 3 && wa == W && n_my == NMY) {   // k_stage12p at N = 1200: ranges of 768 outputs, 6 KB per row, 3 rows per wave
+            rows_pipeline(std::integral_constant<int, 6>{}, std::integral_constant<int, 3>{});
+            return;
+        }
+    }
+    rows_pipeline(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+}
+
 // First stages with a large decimation factor (6 MS/s: m=15/53 taps, 2.56 MS/s: m=20/51 taps) keep more
 // than 128 registers live; they run at a lower occupancy and without the double-buffered LDS reads.
 //
-// MA > 0: stage 3 (decimation MA, TA taps) of the workgroup's OWN range runs as an epilogue.  A workgroup with
-// P == 1 covers SPW whole segments = one contiguous range of RLEN stage-2 outputs for each of its W*CPW channels;
-// every stage-3 output whose window lies inside that range ("interior": all but the ~(TA-1)/MA outputs at each range
-// boundary) is computed here, from the range read back into the LDS the tiles no longer need (the range was written
-// by this workgroup's own waves, so it comes back under workgroup-scope ordering: s_waitcnt vmcnt(0) + barrier), and
-// goes to y3_out[ch][rr].  k_tail4 computes the boundary outputs from the stage-2 scratch and runs the last stage.
+// MA > 0: stage 3 (decimation MA, TA taps) of the workgroup's OWN range runs as an epilogue (stage3_epilogue above).
 template <int M1, int T1, int M2, int T2, int Y2B, int W, int CPW, int MA = 0, int TA = 1>
 __global__ __launch_bounds__(kWave * W, (M1 > 6 ? 1 : 4))
 void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
@@ -563,82 +697,13 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
     store_y2(a.nb - 1);   // the last body's outputs
 
     if constexpr (MA > 0) {
-        static_assert(Y2B == 4, "fused stage 3: groups of 4 stage-2 outputs (two 16-byte pieces)");
-        constexpr int LDS_BYTES = 2 * G::buf_bytes;
-        const int seg_y2 = a.nb * Y2B;                       // stage-2 outputs per segment (P == 1: nb = bodies per segment)
-        const int rlen = SPW * seg_y2;                       // ... per workgroup range
-        const int base = g * rlen;                           // first stage-2 output (index within the call) of this range
-        const int end = min(base + rlen, a.n_y2_new);
-        // interior outputs rr_lo .. rr_hi: window [MA*rr + c0 - (TA-1), MA*rr + c0] inside [base, end)
-        const int rr_lo = (base + (TA - 1) - a.c0 + MA - 1) / MA;
-        const int rr_hi = (end - 1 - a.c0 >= 0) ? min((end - 1 - a.c0) / MA, a.n_y3 - 1) : -1;
-        const int n_int = rr_hi - rr_lo + 1;
-        const int npc = rlen / 2;                            // 16-byte pieces of one channel's range
-        const int cpp = min(W * CPW, LDS_BYTES / (rlen * 8));    // channels per pass (host: >= 1)
-        // every store of this workgroup's range has left its wave, and every wave is done with the tiles
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const v2f *__restrict__ lds2 = reinterpret_cast<const v2f *>(lds);
-        constexpr int NT = kWave * W;
-        // Every instruction here competes for issue slots with two other workgroups' main loops (the CU's vector issue
-        // is 86 % busy), so what does not depend on the channel is computed once: the lanes' LDS-DMA source offsets
-        // (the first NS of them kept in registers) and the lanes' window offsets.
-        const float rcp_seg = __builtin_amdgcn_rcpf((float)seg_y2);
-        auto source_offset = [&](int d0) -> uint32_t {       // LDS piece d0 + lane (samples 2d, 2d+1 in time order) <- where k_stage12 stored it
-            const int tt = 2 * min(d0 + lane, npc - 1);
-            const int seg = (int)(((float)tt + 0.5f) * rcp_seg);
-            const int rem = tt - seg * seg_y2;
-            return (uint32_t)((((rem / Y2B) * SPW + seg) * Y2B + (rem % Y2B)) * 8);
-        };
-        constexpr int NS = 8;
-        uint32_t soff[NS];
-#pragma unroll
-        for (int k = 0; k < NS; k++) soff[k] = source_offset(k * kWave);
-        const int n_third = (n_int + 2) / 3;                 // a lane takes outputs kp, kp + n_third, kp + 2 n_third of one channel
-        const float2 *__restrict__ ysrc = y2_out + a.y2_hist + base;
-        for (int cp0 = 0; cp0 < W * CPW; cp0 += cpp) {
-            const int ncp = min(cpp, W * CPW - cp0);
-            const int chb = cg * W * CPW + cp0;              // first channel of this pass
-            // The range of each channel comes back by LDS-DMA, 1 KB per instruction, landing in TIME order (row ci =
-            // rlen samples); wave w fetches channels w, w + W, ... of the pass
-            for (int ci = wave; ci < ncp; ci += W) {
-                const char *grow = reinterpret_cast<const char *>(ysrc + (size_t)min(chb + ci, a.n_ch - 1) * a.y2_stride);
-                char *lrow = lds + (size_t)ci * rlen * 8;
-#pragma unroll
-                for (int k = 0; k < NS; k++) {
-                    if (k * kWave < npc && k * kWave + lane < npc)
-                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + soff[k]), (lds_void *)(uint32_t)(uintptr_t)(lrow + k * kWave * 16), 16, 0, 0);
-                }
-                for (int d0 = NS * kWave; d0 < npc; d0 += kWave) {
-                    if (d0 + lane < npc)
-                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + source_offset(d0)), (lds_void *)(uint32_t)(uintptr_t)(lrow + (size_t)d0 * 16), 16, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            for (int ci = wave; ci < ncp; ci += W) {
-                const int chn = chb + ci;
-                if (chn >= a.n_ch) break;
-                const v2f *__restrict__ lrow = lds2 + ci * rlen;
-                // the first and the last TA-1 outputs of the range, compactly, for k_tail4's boundary outputs
-                constexpr int SE = 2 * (TA - 1);
-                if (lane < SE) seam_out[(size_t)chn * a.seam_stride + g * SE + lane] = *reinterpret_cast<const float2 *>(&lrow[lane < TA - 1 ? lane : rlen - SE + lane]);
-                static_assert(SE <= kWave, "seam entries of one range: one per lane");
-                // interior outputs, three per lane (conflict-free 40-byte lane stride, three alternating accumulation chains)
-                float2 *__restrict__ y3row = y3_out + (size_t)chn * a.y3_stride + rr_lo;
-                const v2f *__restrict__ wrow = lrow + (MA * rr_lo + a.c0 - (TA - 1) - base);
-                for (int kp = lane; kp < n_third; kp += kWave) {
-                    const bool has1 = kp + n_third < n_int, has2 = kp + 2 * n_third < n_int;
-                    const int k1 = has1 ? kp + n_third : kp, k2 = has2 ? kp + 2 * n_third : kp;
-                    v2f r0 = {0.f, 0.f}, r1 = {0.f, 0.f}, r2 = {0.f, 0.f};
-                    folded_fir3_steps<TA>(r0, r1, r2, wrow + MA * kp, wrow + MA * k1, wrow + MA * k2, taps.h3);
-                    y3row[kp] = make_float2(r0.x, r0.y);
-                    if (has1) y3row[k1] = make_float2(r1.x, r1.y);
-                    if (has2) y3row[k2] = make_float2(r2.x, r2.y);
-                }
-            }
-            __syncthreads();
-        }
+        // the wave's channels: places wave, wave + wa, ... of the workgroup's W * CPW
+        int wa, n_my;
+        stage3_split<SPW, Y2B, W>(a, W * CPW, 2 * G::buf_bytes, wa, n_my);
+        const int c_first = cg * W * CPW;
+        const int place = wave + min(lane, n_my - 1) * wa;
+        stage3_epilogue<MA, TA, SPW, Y2B, W, CPW>(a, taps.h3, y2_out, y3_out, seam_out, lds, 2 * G::buf_bytes, g, wave, lane, wa, n_my,
+                                                  (place < W * CPW && c_first + place < a.n_ch) ? c_first + place : -1, c_first);
     }
 }
 
@@ -896,117 +961,21 @@ __device__ __forceinline__ void stage12p_body(const float2 *__restrict__ x_in, c
     store_y2(a.nb - 1);
 
     if constexpr (MA > 0) {
-        // stage 3 of the workgroup's own ranges, as in k_stage12; the workgroup's channels are its slots' A and B
-        static_assert(Y2B == 4, "fused stage 3: groups of 4 stage-2 outputs (two 16-byte pieces)");
-        const int seg_y2 = a.nb * Y2B;
-        const int rlen = SPW * seg_y2;
-        const int base = g * rlen;
-        const int end = min(base + rlen, a.n_y2_new);
-        const int rr_lo = (base + (TA - 1) - a.c0 + MA - 1) / MA;
-        const int rr_hi = (end - 1 - a.c0 >= 0) ? min((end - 1 - a.c0) / MA, a.n_y3 - 1) : -1;
-        const int n_int = rr_hi - rr_lo + 1;
-        const int npc = rlen / 2;
-        constexpr int NCH = 2 * W * CPW;                     // channel places of the workgroup
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const float rcp_seg = __builtin_amdgcn_rcpf((float)seg_y2);
-        auto source_offset = [&](int d0) -> uint32_t {
-            const int tt = 2 * min(d0 + lane, npc - 1);
-            const int seg = (int)(((float)tt + 0.5f) * rcp_seg);
-            const int rem = tt - seg * seg_y2;
-            return (uint32_t)((((rem / Y2B) * SPW + seg) * Y2B + (rem % Y2B)) * 8);
-        };
-        constexpr int NS = 8;
-        uint32_t soff[NS];
-#pragma unroll
-        for (int k = 0; k < NS; k++) soff[k] = source_offset(k * kWave);
-        const int n_third = (n_int + 2) / 3;
-        const float2 *__restrict__ ysrc = y2_out + a.y2_hist + base;
+        // stage 3 of the workgroup's own ranges; its channels are its slots' A and B: place i = slot i/2, A or B
         const int sbase = cg * W * CPW;                      // first slot of the workgroup
-        auto place_channel = [&](int i) -> int {             // place i = slot i/2, A or B; -1: empty
+        auto place_channel = [&](int i) -> int {             // -1: empty
             const int s = sbase + (i >> 1);
             if (s >= pa.n_slots) return -1;
             const int2 sp = pa.slots[s];
             return (i & 1) ? sp.y : sp.x;
         };
-        // Every wave works through its own places (wave, wave + W, ...) with its own LDS rows: the read-back of the
-        // next rows_w - 1 places is in flight while one place's outputs are computed, and no workgroup barrier is
-        // needed after the one above.  (DMA loads return in order: "at most k * ndma outstanding" = all older rows
-        // have landed, whatever the stores in between are doing.)
-        constexpr int NMY = NCH / W;
-        const int ndma = (npc + kWave - 1) / kWave;          // DMA instructions per row
-        const int rslot = ndma * kWave * 16;                 // bytes per row, whole instructions (the last one's spare lanes land in the pad)
-        const int rows_w = min(pa.lds_bytes / rslot / W, NMY);
-        char *const myrows = lds + (size_t)wave * rows_w * rslot;
+        int wa, n_my;                                        // places per wave: wave, wave + wa, ...
+        stage3_split<SPW, Y2B, W>(a, 2 * W * CPW, pa.lds_bytes, wa, n_my);
+        // (read once, here: a global load inside the epilogue's loop would make hipcc wait for vmcnt(0) and drain the DMAs)
+        const int place = wave + min(lane, n_my - 1) * wa;
+        const int mych = place < 2 * W * CPW ? place_channel(place) : -1;
         const int chn0 = __builtin_amdgcn_readfirstlane(place_channel(0));
-        if (chn0 < 0 || rows_w < 1) return;
-        const int mych = place_channel(wave + min(lane, NMY - 1) * W);   // lane i: the wave's i-th channel (read once: a load here would drain the DMAs)
-        // (ndma_tag, rows_tag) = compile-time (ndma, rows_w), or (0, 0): the run-time values.  With constants the loop over
-        // the wave's places unrolls and every wait is an immediate.
-        auto rows_pipeline = [&](auto ndma_tag, auto rows_tag) {
-            constexpr bool CT = decltype(ndma_tag)::value > 0;
-            const int nd = CT ? decltype(ndma_tag)::value : ndma;
-            const int rw = CT ? decltype(rows_tag)::value : rows_w;
-            auto issue_row = [&](int i) {
-                int chn = __builtin_amdgcn_readlane(mych, i);
-                if (chn < 0) chn = chn0;                     // an empty place moves a row all the same (uniform counts) and computes nothing
-                const char *grow = reinterpret_cast<const char *>(ysrc + (size_t)chn * a.y2_stride);
-                char *lrow = myrows + (size_t)(i % rw) * rslot;
-#pragma unroll
-                for (int k = 0; k < NS; k++) {
-                    if (k < nd)
-                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + soff[k]), (lds_void *)(uint32_t)(uintptr_t)(lrow + k * kWave * 16), 16, 0, 0);
-                }
-                if constexpr (!CT || decltype(ndma_tag)::value > NS) {
-                    for (int k = NS; k < nd; k++)
-                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(grow + source_offset(k * kWave)), (lds_void *)(uint32_t)(uintptr_t)(lrow + (size_t)k * kWave * 16), 16, 0, 0);
-                }
-            };
-            auto row_outputs = [&](int i) {
-                const int chn = __builtin_amdgcn_readlane(mych, i);
-                if (chn < 0) return;
-                const v2f *__restrict__ lrow = reinterpret_cast<const v2f *>(myrows + (size_t)(i % rw) * rslot);
-                constexpr int SE = 2 * (TA - 1);
-                static_assert(SE <= kWave, "seam entries of one range: one per lane");
-                if (lane < SE) seam_out[(size_t)chn * a.seam_stride + g * SE + lane] = *reinterpret_cast<const float2 *>(&lrow[lane < TA - 1 ? lane : rlen - SE + lane]);
-                float2 *__restrict__ y3row = y3_out + (size_t)chn * a.y3_stride + rr_lo;
-                const v2f *__restrict__ wrow = lrow + (MA * rr_lo + a.c0 - (TA - 1) - base);
-                for (int kp = lane; kp < n_third; kp += kWave) {
-                    // three neighbouring outputs per lane: their windows overlap, TA + 2 MA samples are read once
-                    const int r = 3 * kp;
-                    v2f win[TA + 2 * MA];
-#pragma unroll
-                    for (int j = 0; j < TA + 2 * MA; j++) win[j] = wrow[MA * r + j];
-                    v2f r0 = {0.f, 0.f}, r1 = {0.f, 0.f}, r2 = {0.f, 0.f};
-                    folded_fir3_steps<TA>(r0, r1, r2, win, win + MA, win + 2 * MA, taps.h3);
-                    y3row[r] = make_float2(r0.x, r0.y);
-                    if (r + 1 < n_int) y3row[r + 1] = make_float2(r1.x, r1.y);
-                    if (r + 2 < n_int) y3row[r + 2] = make_float2(r2.x, r2.y);
-                }
-            };
-            auto step = [&](int i) {
-                wait_vmcnt_le(min(rw - 1, NMY - 1 - i) * nd);
-                row_outputs(i);
-                if (i + rw < NMY) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row's reads are done before it is filled again
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_row(i + rw);
-                }
-            };
-            if constexpr (CT) {
-#pragma unroll
-                for (int i = 0; i < decltype(rows_tag)::value; i++) issue_row(i);
-#pragma unroll
-                for (int i = 0; i < NMY; i++) step(i);
-            } else {
-                for (int i = 0; i < rw; i++) issue_row(i);
-                for (int i = 0; i < NMY; i++) step(i);
-            }
-        };
-        if (ndma == 6 && rows_w == 3)        // N = 1200: ranges of 768 outputs, 6 KB per row
-            rows_pipeline(std::integral_constant<int, 6>{}, std::integral_constant<int, 3>{});
-        else
-            rows_pipeline(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        stage3_epilogue<MA, TA, SPW, Y2B, W, 2 * CPW>(a, taps.h3, y2_out, y3_out, seam_out, lds, pa.lds_bytes, g, wave, lane, wa, n_my, mych, chn0);
     }
 }
 

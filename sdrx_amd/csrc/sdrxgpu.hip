@@ -770,22 +770,24 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     }
 
     // Stage 3 inside the stage-1/2 kernel: possible when the chain's tail is the compiled-in one, every
-    // workgroup covers one contiguous range of stage-2 outputs (P == 1) whose rows fit the LDS the tiles leave, and
+    // workgroup covers one contiguous range of stage-2 outputs (P == 1), the LDS the tiles leave holds one channel's range at least, and
     // the call's range boundaries fit k_tail4's one pass (4 threads each).  Same outputs either way, bit for bit.
     {
         const int SPW = kWave / b->CPW;
         const long long rlen = (long long)SPW * b->bps * k12->Y2B;
         const size_t lds = 2 * (size_t)(SPW + b->W * b->CPW) * (b->SB * 8 + 16);
+        const size_t epilogue_row = ((size_t)rlen / 2 + kWave - 1) / kWave * kWave * 16;     // one channel's range, whole DMA instructions
         const long long n_bnd_max = (max_y2 + rlen - 1) / rlen;
         const int max_y3 = k12->MA ? max_y2 / k12->MA + 2 : 0;
         const size_t t4_lds = ((size_t)((k12->TB - 1 + 15) / 16) * 16 + max_y3 + 2) * sizeof(float2);   // k_tail4: [hist3 | y3] of one channel
         const bool can = k12->fn_fused && cfg->n_stages == 4 && (int)b->m[2] == k12->MA && (int)b->ntaps[2] == k12->TA &&
                          (int)b->m[3] == k12->MB && (int)b->ntaps[3] == k12->TB && b->P == 1 && !b->pipelined &&
-                         (size_t)rlen * sizeof(float2) <= lds && n_bnd_max <= 64 && !b->tail_generic && t4_lds <= 64 * 1024;
+                         epilogue_row <= lds && n_bnd_max <= 64 && !b->tail_generic && t4_lds <= 64 * 1024;
         if (tune.fused_tail == 2 && !can) {
             free_bank(b);
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.fused_tail = 2, but this bank cannot run stage 3 fused "
-                        "(chain tail, P = %d, pipelined = %d, range of %lld outputs vs %zu B of LDS)", b->P, (int)b->pipelined, rlen, lds);
+                        "(chain tail, P = %d, pipelined = %d, range of %lld outputs: %zu B per row, %zu B of LDS)",
+                        b->P, (int)b->pipelined, rlen, epilogue_row, lds);
         }
         b->fused = can && tune.fused_tail != 1;
         if (b->fused) {
@@ -817,11 +819,11 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     // looked for inside each host part: first channels whose tables are exact complex conjugates of each other
     // (+k / -k steps from the tuner: they share the mixer), then whatever is left, two by two.
     {
-        // (fused: every wave of a workgroup reads its channels' ranges back into LDS rows of its own, one at least)
+        // (fused: the waves of a workgroup read their channels' ranges back into LDS rows of their own, one row at least)
         const size_t epilogue_row = ((size_t)(kWave / b->CPW) * b->bps * k12->Y2B / 2 + kWave - 1) / kWave * kWave * 16;
         const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && b->W == kPairW &&
                          b->CPW == kPairCPW && !b->pipelined && N > 0 &&
-                         (!b->fused || (k12->MA == 5 && k12->TA == 21 && k12p_lds_bytes() / epilogue_row >= (size_t)kPairW));
+                         (!b->fused || (k12->MA == 5 && k12->TA == 21 && epilogue_row <= k12p_lds_bytes()));
         if (tune.pair_lanes == 2 && !can) {
             free_bank(b);
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.pair_lanes = 2, but this bank cannot run two channels per lane "

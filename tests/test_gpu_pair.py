@@ -110,27 +110,28 @@ def test_pair_lanes_with_ftfir_squelch_fm_and_audio_fir():
     assert np.array_equal(want[1].view(np.uint32), got[1].view(np.uint32))
 
 
-@pytest.mark.parametrize("mult,pair_ok", [(2, True), (4, False)])
-def test_longer_translator_tables_change_the_epilogue_rows(mult, pair_ok):
-    """Translator tables of 2 N and 4 N entries (a finer grid): a lane's segment is as long as the table, so the ranges the
-    fused epilogue reads back grow to 12 KB / 24 KB per channel.  With 12 KB every wave of k_stage12p still has one LDS
-    row of its own; with 24 KB it has none and the bank must refuse two channels per lane with fused stage 3 (and run
-    them one per lane).  Same bits on every path."""
+@pytest.mark.parametrize("mult,fits", [(2, True), (4, True), (16, False)])
+def test_longer_translator_tables_change_the_epilogue_rows(mult, fits):
+    """Translator tables of 2 N, 4 N and 16 N entries (a finer grid): a lane's segment is as long as the table, so the
+    ranges the fused epilogue reads back grow to 12 KB / 24 KB / 98 KB per channel.  With 12 KB every wave of k_stage12p
+    still has an LDS row of its own; with 24 KB only three of the four waves have one and share the channels out among
+    themselves; 98 KB do not fit and such a bank must refuse fused stage 3 (and run the separate tail).  Same bits on
+    every path."""
     ch = chains.chain("10")
     offs = [5, -5, 17, -17, 0, 33, 2 * ch.N - 1, -(2 * ch.N - 1), 9]
     N = mult * ch.N
     tabs = [sb.make_translator(N, ch.z, o) if o else None for o in offs]
     L = ch.block_len
-    stream = synth.synth_iq(77, 0, L + 4 * N + 123, 0.25)
+    stream = synth.synth_iq(77, 0, L + 4 * ch.N + 123, 0.25)
     lens = [L, 0, 625, 10 ** 9]
     want = _run(ch, tabs, _cut(stream, lens), OFF, sb.FUSED_OFF)
-    if pair_ok:
+    if fits:
         got = _run(ch, tabs, _cut(stream, lens), REQ, sb.FUSED_REQUIRE)
         assert got[2].pair_lanes >= 1 and got[2].fused_tail
     else:
         with pytest.raises(sb.SdrxGpuError):
             _run(ch, tabs, _cut(stream, lens), REQ, sb.FUSED_REQUIRE)
-        got = _run(ch, tabs, _cut(stream, lens), 0, sb.FUSED_REQUIRE)      # automatic: one channel per lane, still fused
-        assert got[2].pair_lanes == 0 and got[2].fused_tail
+        got = _run(ch, tabs, _cut(stream, lens), REQ, 0)                   # automatic: two channels per lane, separate tail
+        assert got[2].pair_lanes >= 1 and not got[2].fused_tail
     assert np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32))
     assert np.array_equal(want[1].view(np.uint32), got[1].view(np.uint32))
