@@ -205,6 +205,26 @@ def test_full_size_10k_channels_properties_and_sampled_oracle(oracle):
     bank.reset()
     iq2, _ = bank.process(blocks[0] * np.float32(2.0), want_audio=False)
     assert np.array_equal((iq[:, :512] * np.float32(2.0)).view(np.uint32), iq2.view(np.uint32))
+    # (4) a real-valued input makes mirror channels (+k / -k steps: exactly conjugate tables) exact conjugates of each
+    #     other -- whichever lanes, workgroups and kernels the two happen to run in -- with identical audio
+    first = {}
+    for c, o in enumerate(offs):
+        first.setdefault(int(o), c)
+    pairs = [(first[o], first[-o]) for o in range(1, ch.N // 2) if o in first and -o in first]
+    assert len(pairs) == ch.N // 2 - 1
+    cp, cm = np.array([p for p, _ in pairs]), np.array([m for _, m in pairs])
+    conj_tables = all(np.array_equal(tabs[p].view(np.uint32), np.conj(tabs[m]).view(np.uint32)) for p, m in pairs[:50])
+    print("10k: mirror-channel property", "checked" if conj_tables else "SKIPPED (libm's cexpf is not exactly odd/even on this box)")
+    if conj_tables:
+        bank.reset()
+        xr = blocks[0].copy()
+        xr.imag = 0
+        iqr, aur = bank.process(xr)
+        assert np.array_equal(iqr[cp].view(np.uint32), np.conj(iqr[cm]).view(np.uint32))
+        assert np.array_equal(aur[cp].view(np.uint32), aur[cm].view(np.uint32))
+        # ... and so are their later instances (other workgroups, other host parts)
+        far = [(p + 7 * ch.N, m + 3 * ch.N) for p, m in pairs[::37]]
+        assert all(np.array_equal(iqr[p].view(np.uint32), np.conj(iqr[m]).view(np.uint32)) for p, m in far)
     bank.close()
 
 
