@@ -425,8 +425,8 @@ def main():
                     sb.host_unregister(a_)
         hb.close()
         host_path = {"what": f"sdrxgpu_bank_process: {L * 8 / 1e6:.2f} MB H2D + {n_ch * 512 * 12 / 1e6:.1f} MB D2H per block "
-                             f"({n_ch * 512 * 4 / 1e6:.1f} MB audio-only), outputs complete on return; the bank runs as two channel "
-                             f"halves so that the D2H of the first overlaps the kernels of the second",
+                             f"({n_ch * 512 * 4 / 1e6:.1f} MB audio-only), outputs complete on return; the bank runs in channel "
+                             f"parts (4 at 10 000 channels) so that the D2H of one part overlaps the kernels of the next",
                      "unit": "Mch-samples/s", **res}
 
     if rank == 0:
@@ -440,10 +440,10 @@ def main():
         ach_tf = f12 * units / (k12_ms / 1e3) / 1e12 if k12_n else None
         prof, prof_src = profile_facts(n_ch, fused, pair_seen[n_ch])
         n_y2, n_y3 = L // (ch.stages[0].m * ch.stages[1].m), L // (ch.stages[0].m * ch.stages[1].m * ch.stages[2].m)
-        if fused:     # k_tail4: [hist3 | y3] + the range-boundary buffer in, decimated IQ out twice (caller's buffer + the AGC's)
-            tail_bytes = n_ch * (8.0 * (n_y3 + 80) + 8.0 * 40 * ((n_y2 + 767) // 768) + 2 * 8.0 * 512)
-        else:         # k_tail_s: the stage-2 scratch in, decimated IQ out twice
-            tail_bytes = n_ch * (8.0 * n_y2 + 2 * 8.0 * 512)
+        if fused:     # k_tail4: [hist3 | y3] + the range-boundary buffer in, decimated IQ out (k_agc reads the caller's rows)
+            tail_bytes = n_ch * (8.0 * (n_y3 + 80) + 8.0 * 40 * ((n_y2 + 767) // 768) + 8.0 * 512)
+        else:         # k_tail_s: the stage-2 scratch in, decimated IQ out
+            tail_bytes = n_ch * (8.0 * n_y2 + 8.0 * 512)
         kern = {
             "k_stage12": {"ms": k12_ms, "bound": "valu_fp32", "flops_per_unit": f12, "achieved_tflops": ach_tf,
                           "frac": ach_tf / FP32_PEAK_TF if ach_tf else None,
