@@ -1,8 +1,9 @@
 """Fuzz on the GPU (not collected by pytest; run by hand: `python tests/fuzz_gpu.py <seed> <seconds>` from the repo root).
 Random banks (chain, channel count, offset pattern), call splits, body layouts and LF-AGC: the default path (two channels
 per lane, stage 3 fused, IQ rows read in place -- whatever bank_create picks) against one channel per lane + separate
-tail, bit for bit, and three channels of every case against the oracle (1e-5).  Round 2: 10 355 cases in 240 s on one
-MI355X, 3 462 of them on the fused path, no failure."""
+tail, bit for bit; half of the cases also through the device-pointer entry with the caller's rows at a random stride; and
+three channels of every case against the oracle (1e-5).  Round 2: 10 355 + 5 487 cases in 240 + 150 s on one MI355X
+(a third of them on the fused path), no failure."""
 import os
 import random
 import sys
@@ -52,6 +53,27 @@ while time.time() < t_end:
     except sb.SdrxGpuError as e:
         print("refused:", rate, n_ch, kind, hint, str(e)[:100]); continue
     ok = np.array_equal(a[0].view(np.uint32), g[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), g[1].view(np.uint32))
+    # the device-pointer entry with the caller's rows at a random stride (even: k_agc reads the IQ rows in place; odd: the
+    # compact copy), whole calls of at most one block
+    if rng.random() < 0.5 and all(len(x) <= L for x in cuts):
+        import torch
+        stride = rng.choice([512, 513, 514, 515, 516, 640])
+        b = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=hint, lf_agc=lf)
+        d_iq = torch.zeros(n_ch, stride, 2, dtype=torch.float32, device="cuda")
+        d_au = torch.zeros(n_ch, stride, dtype=torch.float32, device="cuda")
+        piq, pau = [], []
+        for x in cuts:
+            if len(x) == 0:
+                continue
+            dx = torch.from_numpy(np.ascontiguousarray(x).view(np.float32).reshape(-1, 2)).cuda()
+            n = b.process_device(dx.data_ptr(), len(x), d_iq.data_ptr(), d_au.data_ptr(), stride)
+            b.synchronize()
+            piq.append(d_iq[:, :n].cpu().numpy().view(np.complex64)[..., 0])
+            pau.append(d_au[:, :n].cpu().numpy())
+        b.close()
+        if piq:
+            diq, dau = np.concatenate(piq, 1), np.concatenate(pau, 1)
+            ok = ok and np.array_equal(diq.view(np.uint32), g[0].view(np.uint32)) and np.array_equal(dau.view(np.uint32), g[1].view(np.uint32))
     # oracle on 3 channels
     pick = sorted(set([0, n_ch // 2, n_ch - 1]))
     errs = []
