@@ -727,6 +727,14 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 }
             }
         }
+        // Banks that can take two channels per lane (k_stage12p: 10 MS/s chain, compiled for W = 4, CPW = 4) do: measured at
+        // 1 024 ... 25 000 channels the pair kernel is as fast as or faster than whatever the model above picks for one
+        // channel per lane (1 536: 0.192 against 0.219 ms, 3 000: 0.341 / 0.398, 8 192: 0.811 / 0.942, 25 000: 2.43 / 2.88)
+        if (k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && !b->pipelined && N > 0 &&
+            (tune.pair_lanes == 2 || (tune.pair_lanes == 0 && b->n_ch >= 1024)) && k12_geometry_compiled(k12->level, kPairW, kPairCPW)) {
+            b->W = kPairW;
+            b->CPW = kPairCPW;
+        }
         if (tune.k12_waves) b->W = (int)tune.k12_waves;
         if (tune.k12_cpw) b->CPW = (int)tune.k12_cpw;
         if (!k12_geometry_compiled(k12->level, b->W, b->CPW) ||
