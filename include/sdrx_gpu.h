@@ -164,6 +164,9 @@ typedef struct {
     uint64_t device_bytes;     /* HBM held by the bank */
     uint32_t fused_tail;       /* 1: stage 3 runs inside the stage-1/2 kernel (large banks of the 4-stage chains) */
     uint32_t pair_lanes;       /* > 0: two channels per lane in the stage-1/2 kernel; the number of conjugate pairs + 1 */
+    uint32_t k12_waves;        /* geometry of the stage-1/2 launch as chosen (or forced by tuning): waves per workgroup, */
+    uint32_t k12_cpw;          /*   channels (slots) per wave, */
+    uint32_t k12_bodies;       /*   bodies per lane */
 } sdrxgpu_bank_info;
 
 /* Fill the AGC / LfAGC parameter blocks as sdrx configures them per channel

@@ -69,7 +69,8 @@ class _Cfg(C.Structure):
 class BankInfo(C.Structure):
     _fields_ = [("n_channels", C.c_uint32), ("m_total", C.c_uint32), ("n_translator", C.c_uint32),
                 ("history_len", C.c_uint32), ("samples_in", C.c_uint64), ("samples_out", C.c_uint64),
-                ("device_bytes", C.c_uint64), ("fused_tail", C.c_uint32), ("pair_lanes", C.c_uint32)]
+                ("device_bytes", C.c_uint64), ("fused_tail", C.c_uint32), ("pair_lanes", C.c_uint32),
+                ("k12_waves", C.c_uint32), ("k12_cpw", C.c_uint32), ("k12_bodies", C.c_uint32)]
 
 
 _lib = None

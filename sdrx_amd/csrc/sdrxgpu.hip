@@ -690,42 +690,51 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     // Geometry of the stage-1/2 launch: W waves per workgroup, CPW channels per wave (the wave's 64
     // lanes are CPW channels x 64/CPW time segments), nb bodies per lane.  Every choice computes the same
     // outputs bit for bit (tests/test_gpu_parity.py); the choice only decides how much of the machine does
-    // useful work.  Picked by a small model of one standard block: useful lane-bodies / (lane-bodies the
-    // grid occupies, in whole rounds of resident workgroups), times how well the CU's SIMDs are fed.
+    // useful work.  Picked by a model fitted to a sweep of the 10 MS/s chain over 1 ... 1 023 channels x 9 geometries x
+    // 6 lane lengths: workgroups of 4 waves were the fastest or within 2 % of it at every size, so W = 4;
+    // the busiest CU gets m = ceil(workgroups / CUs) of them, runs them kmax at a time (LDS, registers), and a body
+    // takes body_time(CPW, k) while k workgroups share the CU's SIMDs (fitted, in units of one 4-channel wave alone on
+    // its SIMD); cost = (WU + nb) x that sum.  The kernel keeps a channel group's workgroups on one XCD (blockIdx % 8):
+    // fewer than 8 groups reach only that many XCDs.
     {
         const long long U = ((long long)max_y2 + k12->Y2B - 1) / k12->Y2B;      // body slots per channel per call
-        double best_score = -1.0;
+        double best_cost = -1.0;
         const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        for (int W : {16, 8, 4}) {
-            for (int CPW : {4, 2, 1}) {
-                if (!k12_geometry_compiled(k12->level, W, CPW)) continue;
-                const int SPW = kWave / CPW;
-                const size_t lds = 2 * (size_t)(SPW + W * CPW) * (b->SB * 8 + 16);
-                if (lds > 160 * 1024) continue;
-                const int max_waves_cu = (k12->level == 2) ? 8 : 16;                               // register budget
-                int wg_per_cu = (int)std::min<size_t>(160 * 1024 / lds, (size_t)(max_waves_cu / W));
-                if (wg_per_cu < 1) continue;
-                const double waves_per_simd = wg_per_cu * W / 4.0;
-                const double feed = std::min(1.0, 0.35 + 0.325 * waves_per_simd);          // 1 wave/SIMD ~ 2/3 of peak issue
-                for (int nb = b->bps; nb >= 1; nb--) {
-                    if (b->bps % nb) continue;
-                    const int P = b->bps / nb;
-                    const long long G = (U + (long long)SPW * b->bps - 1) / ((long long)SPW * b->bps);
-                    const long long cgs = ((long long)b->n_ch + W * CPW - 1) / (W * CPW);
-                    const long long wgs = cgs * G * P;
-                    const long long slots = (long long)n_cu * wg_per_cu;
-                    const long long rounds = (wgs + slots - 1) / slots;
-                    const double useful = (double)b->n_ch * (double)U;                       // lane-bodies that produce output
-                    const double spent = (double)rounds * slots * W * kWave * (b->WU + nb);
-                    const double score = useful / spent * feed;
-                    if (score > best_score * 1.0001) {
-                        best_score = score;
-                        b->W = W;
-                        b->CPW = CPW;
-                        b->nb = nb;
-                    }
+        auto body_time = [](int cpw, int k) {
+            if (k <= 0) return 0.0;
+            if (cpw == 4) return k == 1 ? 1.0 : k == 2 ? 1.45 : 1.87 + 0.45 * (k - 3);
+            if (cpw == 2) return k == 1 ? 0.83 : 1.39 + 0.45 * (k - 2);
+            return 0.97 + 0.45 * (k - 1);
+        };
+        const int W = 4;
+        for (int CPW : {4, 2, 1}) {
+            if (!k12_geometry_compiled(k12->level, W, CPW)) continue;
+            const int SPW = kWave / CPW;
+            const size_t lds = 2 * (size_t)(SPW + W * CPW) * (b->SB * 8 + 16);
+            if (lds > 160 * 1024) continue;
+            const int max_waves_cu = (k12->level == 2) ? 8 : 16;                               // register budget
+            const int kmax = (int)std::min<size_t>(160 * 1024 / lds, (size_t)(max_waves_cu / W));
+            if (kmax < 1) continue;
+            for (int nb = b->bps; nb >= 1; nb--) {
+                if (b->bps % nb) continue;
+                const int P = b->bps / nb;
+                const long long G = (U + (long long)SPW * b->bps - 1) / ((long long)SPW * b->bps);
+                const long long cgs = ((long long)b->n_ch + W * CPW - 1) / (W * CPW);
+                const long long wgs = cgs * G * P;
+                const long long cus = std::max<long long>(1, (long long)n_cu * std::min<long long>(8, cgs) / 8);
+                const long long m = (wgs + cus - 1) / cus;
+                const double cost = (double)(b->WU + nb) * ((double)(m / kmax) * body_time(CPW, kmax) + body_time(CPW, (int)(m % kmax)));
+                if (best_cost < 0 || cost < best_cost * 0.9999) {
+                    best_cost = cost;
+                    b->W = W;
+                    b->CPW = CPW;
+                    b->nb = nb;
                 }
             }
+        }
+        if (best_cost < 0) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: no stage-1/2 geometry fits this chain");
         }
         // Banks that can take two channels per lane (k_stage12p: 10 MS/s chain, compiled for W = 4, CPW = 4) do: measured at
         // 1 024 ... 25 000 channels the pair kernel is as fast as or faster than whatever the model above picks for one
@@ -801,7 +810,9 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                         "(chain tail, P = %d, pipelined = %d, range of %lld outputs: %zu B per row, %zu B of LDS)",
                         b->P, (int)b->pipelined, rlen, epilogue_row, lds);
         }
-        b->fused = can && tune.fused_tail != 1;
+        // automatic: from 6 000 channels (measured with whole segments per lane, fused against separate tail: 3 000 channels
+        // 0.345 / 0.340 ms, 5 000: 0.528 / 0.521, 6 144: 0.639 / 0.649, 8 192: 0.825 / 0.853, 10 000: 0.997 / 1.03)
+        b->fused = can && (tune.fused_tail == 2 || (tune.fused_tail == 0 && b->n_ch >= 6000));
         if (b->fused) {
             b->H2 = ((k12->TA - 1 + 15) / 16) * 16;
             b->H3 = ((k12->TB - 1 + 15) / 16) * 16;
@@ -1158,6 +1169,9 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
     info->device_bytes = b->device_bytes;
     info->fused_tail = b->fused ? 1u : 0u;
     info->pair_lanes = b->pair ? (uint32_t)b->n_conj_pairs + 1u : 0u;
+    info->k12_waves = (uint32_t)b->W;
+    info->k12_cpw = (uint32_t)b->CPW;
+    info->k12_bodies = (uint32_t)b->nb;
     return SDRXGPU_OK;
 }
 
