@@ -2,8 +2,9 @@
 Random banks (chain, channel count, offset pattern), call splits, body layouts and LF-AGC: the default path (two channels
 per lane, stage 3 fused, IQ rows read in place -- whatever bank_create picks) against one channel per lane + separate
 tail, bit for bit; half of the cases also through the device-pointer entry with the caller's rows at a random stride; and
-three channels of every case against the oracle (1e-5).  Round 2: 10 355 + 5 487 cases in 240 + 150 s on one MI355X
-(a third of them on the fused path), no failure."""
+three channels of every case against the oracle (1e-5); all nine chains, --ftfir on the two 4-stage ones.  Round 2:
+10 355 + 5 487 + 4 193 + 8 387 cases in 240 + 150 + 120 + 200 s on one MI355X (a third of the 10 MS/s cases on the
+fused path), no failure."""
 import os
 import random
 import sys
@@ -19,7 +20,8 @@ rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 60
 n_cases = 0
 while time.time() < t_end:
-    rate = rng.choice(["10"] * 6 + ["2.4", "1.2"])
+    rate = rng.choice(["10"] * 6 + ["2.4", "2.4", "1.2", "0.96", "1.44", "1.6", "1.92", "6", "2.56"])
+    ftfir = rate in ("10", "2.4") and rng.random() < 0.15
     ch = chains.chain(rate)
     n_ch = rng.choice([1, 2, 3, 17, 31, 32, 33, 64, 65, 100, 257, 1023, 1024, 1025, 1500, 2049, 3000])
     kind = rng.choice(["cycled", "random", "mirror", "same"])
@@ -42,7 +44,7 @@ while time.time() < t_end:
     hint = rng.choice([0, 0, WHOLE])
     lf = rng.random() < 0.3
     def run(tuning, hint_):
-        b = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=hint_, lf_agc=lf, tuning=tuning)
+        b = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=hint_, lf_agc=lf, ftfir=ftfir, tuning=tuning)
         info = b.info()
         outs = [b.process(x) for x in cuts]
         b.close()
@@ -58,7 +60,7 @@ while time.time() < t_end:
     if rng.random() < 0.5 and all(len(x) <= L for x in cuts):
         import torch
         stride = rng.choice([512, 513, 514, 515, 516, 640])
-        b = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=hint, lf_agc=lf)
+        b = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=hint, lf_agc=lf, ftfir=ftfir)
         d_iq = torch.zeros(n_ch, stride, 2, dtype=torch.float32, device="cuda")
         d_au = torch.zeros(n_ch, stride, dtype=torch.float32, device="cuda")
         piq, pau = [], []
@@ -78,11 +80,11 @@ while time.time() < t_end:
     pick = sorted(set([0, n_ch // 2, n_ch - 1]))
     errs = []
     for c in pick:
-        y = orc.msd(tabs[c], ch.stage_tuples()).decimate(stream)
+        y = orc.msd(tabs[c], ch.stage_tuples(), use_ftfir=ftfir and tabs[c] is not None).decimate(stream)
         den = np.maximum(np.abs(y), np.sqrt(np.mean(np.abs(y) ** 2)) + 1e-30)
         errs.append(float(np.max(np.abs(g[0][c, :len(y)] - y) / den)) if len(y) else 0.0)
     n_cases += 1
-    print(("OK  " if ok and max(errs) < 1e-5 else "FAIL"), rate, "n_ch", n_ch, kind, "hint", hint != 0, "lf", lf, "calls", len(cuts), "pair", g[2].pair_lanes, "fused", g[2].fused_tail, "oracle %.2e" % max(errs), flush=True)
+    print(("OK  " if ok and max(errs) < 1e-5 else "FAIL"), rate + ("/ftfir" if ftfir else ""), "n_ch", n_ch, kind, "hint", hint != 0, "lf", lf, "calls", len(cuts), "pair", g[2].pair_lanes, "fused", g[2].fused_tail, "oracle %.2e" % max(errs), flush=True)
     if not (ok and max(errs) < 1e-5):
         sys.exit(1)
 print("cases", n_cases)
