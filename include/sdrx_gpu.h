@@ -95,7 +95,8 @@ typedef struct {
     uint32_t k12_cpw;        /* channels per wave of that kernel: 1, 2 or 4; 0 = auto                         */
     uint32_t tail_tile;      /* final outputs per workgroup of the separate tail kernel, 8..128; 0 = auto     */
     uint32_t tail_generic;   /* 1 = run-time-tap tail kernel even where a compile-time one exists             */
-    uint32_t fused_tail;     /* 0 = auto; 1 = never run stage 3 inside the stage-1/2 kernel; 2 = require it   */
+    uint32_t fused_tail;     /* 0 = auto (from 6 000 channels, where it is the faster path); 1 = never run stage 3
+                                inside the stage-1/2 kernel; 2 = require it                                      */
     uint32_t host_parts;     /* channel parts of sdrxgpu_bank_process (D2H of one beside the kernels of the next):
                                 0 = auto, 1..8                                                                */
     uint32_t pair_lanes;     /* two channels per lane of the stage-1/2 kernel (conjugate partners share the mixer):
