@@ -142,3 +142,38 @@ def test_blocks_placed_in_both_input_rings_ahead_of_time():
         assert np.array_equal(d_au.cpu().numpy().view(np.uint32), want[k][1].view(np.uint32))
         p_cur = p_next
     bank.close()
+
+
+@pytest.mark.parametrize("fm", [False, True])
+@pytest.mark.parametrize("stride", [512, 513, 516])
+def test_device_entry_reads_the_callers_iq_rows_in_place_squelch_and_fm(stride, fm):
+    """With 16-byte aligned rows (even stride) k_agc and k_squelch read the decimated IQ from the caller's buffer and no
+    compact copy is written; with an odd stride they read the copy.  Either way the outputs are those of the host entry,
+    bit for bit -- also for banks with squelch (FFT of the pre-AGC rows) and FM channels."""
+    ch = chains.chain("10")
+    L = ch.block_len
+    offs = [37, -100, 5, 0, 77, -77] * 20
+    levels = np.array([9.0, 0.0, 9.0, 3.0, 9.0, 0.0] * 20, np.float32)
+    tabs = sb.translators_for(ch, offs)
+    pb, ru, rd = chains.squelch_tables()
+    on = [False, True, True, False]
+    blocks = [synth.synth_iq(5, b * L, L, 0.25, [tabs[0]] if c else [], [0.2] if c else [], ch.N, 10000) for b, c in enumerate(on)]
+    kw = {"squelch": (levels, pb, ru, rd)}
+    if fm:
+        kw["modulation"] = ["FM" if i % 3 == 0 else "AM" for i in range(len(offs))]
+    a = sb.ChannelBank(tabs, ch.stage_tuples(), **kw)
+    ref = [a.process(x) for x in blocks]
+    a.close()
+    b = sb.ChannelBank(tabs, ch.stage_tuples(), **kw)
+    d_iq = torch.zeros(len(offs), stride, 2, dtype=torch.float32, device="cuda")
+    d_au = torch.zeros(len(offs), stride, dtype=torch.float32, device="cuda")
+    for x, (riq, rau) in zip(blocks, ref):
+        dx = torch.from_numpy(np.ascontiguousarray(x).view(np.float32).reshape(-1, 2)).cuda()
+        n = b.process_device(dx.data_ptr(), len(x), d_iq.data_ptr(), d_au.data_ptr(), stride)
+        b.synchronize()
+        assert n == 512
+        giq = d_iq[:, :n].cpu().numpy().view(np.complex64)[..., 0]
+        gau = d_au[:, :n].cpu().numpy()
+        assert np.array_equal(giq.view(np.uint32), riq.view(np.uint32))
+        assert np.array_equal(gau.view(np.uint32), rau.view(np.uint32))
+    b.close()
