@@ -293,6 +293,12 @@ def main():
     if args.selftest_launch:
         selftest_launch(args)               # does not return
 
+    # HIP maps streams onto 4 hardware queues by default; a process that has had more streams than that (this one: torch's,
+    # and two per bank) can end up with two banks' compute streams on ONE queue, and their kernels then run one after the
+    # other instead of side by side (measured, tools/two_streams.py: 0.24 ms per step of two 1 024-channel banks with
+    # distinct queues, 0.33 when they collide; 8 queues: 0.26 either way).  Must be set before the HIP runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
     import numpy as np
     import torch  # before libsdrxgpu: it then binds to the HIP runtime torch ships (one runtime per process)
     from sdrx_amd import bank as sb
@@ -387,11 +393,13 @@ def main():
             for i in range(n_streams):
                 banks[i].process_pinned(hosts[i].data_ptr(), L, outs[i][0].data_ptr(), outs[i][1].data_ptr(), 512)
 
-        for _ in range(args.warmup + 20):
+        # (warm-up long enough for the clock to settle: ~75 ms of this load -- timed 20 steps after the light configurations
+        # above, the loop read 0.33-0.38 ms where it runs at 0.24)
+        for _ in range(args.warmup + 300):
             multi_step()
         for bk in banks:
             bk.synchronize()
-        n_it = max(10, args.steps)
+        n_it = max(300, args.steps)
         t0 = time.perf_counter()
         for _ in range(n_it):
             multi_step()
