@@ -19,7 +19,7 @@ def t(tabs, n_ch, **kw):
     ms,n=bk.profile_read(sb.K_STAGE12); k12=ms/max(n,1)
     ms,n=bk.profile_read(sb.K_TAIL); kt=ms/max(n,1)
     i=bk.info(); bk.close(); return k12, kt, i.fused_tail
-out=open("gpurun_out/sweep5.jsonl","w")
+out=open("gpurun_out/geometry_sweep.jsonl","w")
 for n_ch in (1, 8, 16, 32, 64, 96, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1000, 1023):
     offs=chains.offsets_cycled(n_ch, ch.N); tabs=sb.translators_for(ch,offs)
     for w,c in ((16,4),(16,2),(16,1),(8,4),(8,2),(8,1),(4,4),(4,2),(4,1)):
