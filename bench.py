@@ -44,6 +44,9 @@ def parse_args(argv=None):
     ap.add_argument("--block-hint", type=int, default=0)
     ap.add_argument("--fused", type=int, default=0, help="tuning.fused_tail: 0 auto, 1 separate tail kernel, 2 require the fused path")
     ap.add_argument("--pair", type=int, default=0, help="tuning.pair_lanes: 0 auto, 1 one channel per lane, 2 require two channels per lane")
+    ap.add_argument("--matrix", type=int, default=0, help="tuning.matrix_pipe: 0 auto, 1 vector kernels only, 2 require k_stage12m (mixer + stage 1 on the f32 matrix pipe)")
+    ap.add_argument("--mgs", type=int, default=0, help="tuning.m_slot_groups (k_stage12m workgroup shape), 0 auto")
+    ap.add_argument("--mgt", type=int, default=0, help="tuning.m_seg_groups, 0 auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--pipelined", action="store_true",
@@ -336,9 +339,12 @@ def main():
                          for b in range(n_ring)])
         ring = torch.from_numpy(host).cuda()
 
-    tuning = {"fused_tail": args.fused, "pair_lanes": args.pair} if (args.fused or args.pair) else None
+    tuning = None
+    if args.fused or args.pair or args.matrix or args.mgs or args.mgt:
+        tuning = {"fused_tail": args.fused, "pair_lanes": args.pair, "matrix_pipe": args.matrix, "m_slot_groups": args.mgs, "m_seg_groups": args.mgt}
     fused_seen = {}
     pair_seen = {}
+    matrix_seen = {}
 
     def run(offsets, steps, warmup, events=True):
         tabs = sb.translators_for(ch, offsets)
@@ -346,6 +352,7 @@ def main():
                               pipelined=args.pipelined, tuning=tuning)
         fused_seen[len(offsets)] = int(bank.info().fused_tail)
         pair_seen[len(offsets)] = int(bank.info().pair_lanes)
+        matrix_seen[len(offsets)] = int(bank.info().matrix_pipe)
         # N > 1: the broadcasts land directly in the bank's two input rings, alternately (their addresses repeat
         # for whole blocks), so process_device finds each block in place; any other address would be copied in
         p0, cap = bank.ingest_buffer()
@@ -487,7 +494,8 @@ def main():
                                 if (world > 1 or args.force_dist) else ""),
                 "kernel_path": ("stage 3 fused behind stages 1-2 (k_stage12 + k_tail4 + k_agc)" if fused else
                                 "separate tail (k_stage12 + k_tail_s + k_agc)") +
-                               (f"; two channels per lane in k_stage12, {pair_seen[n_ch] - 1} conjugate pairs share the mixer" if pair_seen[n_ch] else ""),
+                               (f"; two channels per lane in k_stage12, {pair_seen[n_ch] - 1} conjugate pairs share the mixer" if pair_seen[n_ch] else "") +
+                               ("; mixer + stage 1 on the f32 matrix pipe (k_stage12m)" if matrix_seen[n_ch] else ""),
                 "realtime_factor": value * 1e6 / (n_ch * world * ch.fs),
                 "settle_steps": SETTLE_STEPS,    # untimed, before the W warm-up steps (clock settling, see time_bank)
                 "call_semantics": "drop-in: call k returns block k" if not args.pipelined else

@@ -88,8 +88,9 @@ typedef struct {
 } sdrxgpu_agc_params;
 
 /* Geometry / kernel-path overrides for tests and tuning runs.  NULL in sdrxgpu_bank_cfg.tuning (the default) =
- * everything automatic.  Every choice computes the same outputs (tests/test_gpu_parity.py); a choice whose
- * tiles do not fit the CU's LDS, or that is not compiled for the chain, makes sdrxgpu_bank_create fail. */
+ * everything automatic.  Every choice but matrix_pipe computes the same outputs bit for bit
+ * (tests/test_gpu_parity.py); a choice whose tiles do not fit the CU's LDS, or that is not compiled for the chain,
+ * makes sdrxgpu_bank_create fail. */
 typedef struct {
     uint32_t k12_waves;      /* waves per workgroup of the stage-1/2 kernel: 4, 8 or 16; 0 = auto            */
     uint32_t k12_cpw;        /* channels per wave of that kernel: 1, 2 or 4; 0 = auto                         */
@@ -101,6 +102,11 @@ typedef struct {
                                 0 = auto, 1..8                                                                */
     uint32_t pair_lanes;     /* two channels per lane of the stage-1/2 kernel (conjugate partners share the mixer):
                                 0 = auto, 1 = never, 2 = require                                              */
+    uint32_t matrix_pipe;    /* mixer + stage 1 of the 10 MS/s chain on the f32 matrix pipe (k_stage12m: exact fp32
+                                fma chains in another summation order -- the one choice here whose outputs differ
+                                from the others', by rounding only): 0 = auto, 1 = never, 2 = require            */
+    uint32_t m_slot_groups;  /* k_stage12m workgroup = m_slot_groups x m_seg_groups tiles (waves) of 16 channel    */
+    uint32_t m_seg_groups;   /*   pairs x 16 time segments: (2,2), (4,2) or (2,4); 0 = auto                        */
 } sdrxgpu_tuning;
 
 typedef struct {
@@ -168,6 +174,8 @@ typedef struct {
     uint32_t k12_waves;        /* geometry of the stage-1/2 launch as chosen (or forced by tuning): waves per workgroup, */
     uint32_t k12_cpw;          /*   channels (slots) per wave, */
     uint32_t k12_bodies;       /*   bodies per lane */
+    uint32_t matrix_pipe;      /* 1: mixer + stage 1 run on the f32 matrix pipe (k_stage12m) */
+    uint32_t m_slots;          /*   its channel-pair slots (pairs + channels without partner + padding) */
 } sdrxgpu_bank_info;
 
 /* Fill the AGC / LfAGC parameter blocks as sdrx configures them per channel

@@ -45,7 +45,8 @@ class AgcParams(C.Structure):
 
 class Tuning(C.Structure):
     """sdrxgpu_tuning: geometry / kernel-path overrides for tests and tuning runs (0 = automatic)."""
-    _fields_ = [(k, C.c_uint32) for k in ("k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail", "host_parts", "pair_lanes")]
+    _fields_ = [(k, C.c_uint32) for k in ("k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail", "host_parts", "pair_lanes",
+                                            "matrix_pipe", "m_slot_groups", "m_seg_groups")]
 
 
 FUSED_AUTO, FUSED_OFF, FUSED_REQUIRE = 0, 1, 2
@@ -70,7 +71,8 @@ class BankInfo(C.Structure):
     _fields_ = [("n_channels", C.c_uint32), ("m_total", C.c_uint32), ("n_translator", C.c_uint32),
                 ("history_len", C.c_uint32), ("samples_in", C.c_uint64), ("samples_out", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("fused_tail", C.c_uint32), ("pair_lanes", C.c_uint32),
-                ("k12_waves", C.c_uint32), ("k12_cpw", C.c_uint32), ("k12_bodies", C.c_uint32)]
+                ("k12_waves", C.c_uint32), ("k12_cpw", C.c_uint32), ("k12_bodies", C.c_uint32),
+                ("matrix_pipe", C.c_uint32), ("m_slots", C.c_uint32)]
 
 
 _lib = None

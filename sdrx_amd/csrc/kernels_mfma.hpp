@@ -1,0 +1,314 @@
+// kernels_mfma.hpp -- k_stage12m: the NCO mixer and decimator stage 1 of the 10 MS/s chain on the f32 matrix pipe
+// (v_mfma_f32_16x16x4_f32), decimator stage 2 on the vector pipe.  Same job, inputs and outputs as k_stage12p
+// (kernels.hpp); reference: MSD::decimate mixer path src/msd.hpp:132-155, S::addSample / calculateOutput
+// msd.hpp:228-335, translator table sdrx.cpp:1682-1690.
+//
+// Why a matrix instruction fits a 1-D FIR here.  The mixer and the first FIR are one linear map per channel,
+//     y1_c[k] = sum_i h1[i] * t_c[(5k-12+i) mod N] * x[5k-12+i],          i = 0 .. 16,
+// and for time segments that start a multiple of N samples apart the coefficient h1[i]*t_c[..] is the same in every
+// segment.  So for 16 channels x 16 such segments, stage-1 output k of all of them is a dense 16 x 17 by 17 x 16
+// product: A[channel][tap] = h1[tap] * t_c[..] (built on the fly from the caller's table -- float-rounded phases and
+// all), B[tap][segment] = x.  Channels at +k and -k steps from the tuner have exactly conjugate tables
+// (k_stage12p's observation), so with A split into its real part Cr and imaginary part Ci the four REAL products
+//     Pr = Cr xr,  Pi = Cr xi,  Qr = Ci xr,  Qi = Ci xi
+// give both channels: y+ = (Pr - Qi) + j (Pi + Qr),  y- = (Pr + Qi) + j (Pi - Qr): 68 multiply-adds per pair of
+// complex outputs against 98 lane-slots in the packed vector form, no separate mixer pass, and the matrix pipe holds
+// 2.4 GHz where packed fp32 vector code runs at 1.8 (measured: tools/ubench_mfma_fir.hip).  The f32 MFMA
+// is an exact fp32 fma chain (one rounding per product, k-ordered), not a reduced-precision path.
+//
+// A channel without partner runs as a pair whose second half is dropped: its bits do not depend on who else is in the
+// bank.  Taps 0..15 go through four K = 4 steps; tap 16 starts the accumulators (vector multiply), which costs less
+// issue time than a fifth, mostly empty K step (the f32 MFMA and the vector ALU do not overlap: measured additive).
+//
+// Geometry.  A wave = one tile of 16 slots (pairs) x 16 time segments (MFMA M x N); lanes hold C/D as
+// [slot 4*(lane>>4)+r][segment lane&15], r = 0..3.  A workgroup = GS slot groups x GT segment groups = GS*GT waves that
+// share GT*16 input rows and GS*16 translator rows in LDS (LDS-DMA, two buffers of half a body = 50 samples + 12 of
+// history each).  Segments, bodies (100 samples = 20 stage-1 outputs = 4 stage-2 outputs), warm-up and the body-major
+// stage-2 scratch are k_stage12's, so the tail kernels do not know which kernel ran.
+// Stage 2 (19 taps, /5) runs in TRANSPOSED form: a stage-1 output is multiplied into the (at most four) stage-2 outputs
+// whose windows hold it, so a lane carries 4 accumulators per value instead of a 14-deep delay line -- what makes 8
+// channel-segments per lane fit the register file.  Each output is still one fma chain over its 19 inputs in order
+// j = 0..18, whatever body, lane or call it falls in: splitting the stream differently changes no bit.
+#pragma once
+#include "kernels.hpp"
+
+namespace sdrxgpu {
+
+template <int GS, int GT>
+struct TileGeomM {
+    static constexpr int HB = 50;                       // input samples per half-body
+    static constexpr int PH = 10;                       // stage-1 outputs ("phases") per half-body
+    static constexpr int HALO = 12;                     // T1 - M1: samples in front of a half-body its first window needs
+    static constexpr int row_bytes = 528;               // 62 samples = 496 B, padded: pitch == 16 (mod 32) keeps the operand reads conflict-free
+    static constexpr int pieces_a = 33, pieces_b = 31;  // one DMA instruction = two adjacent rows: 33 + 31 16-byte pieces
+    static constexpr int x_rows = GT * 16, t_rows = GS * 16;
+    static constexpr int buf_bytes = (x_rows + t_rows) * row_bytes;
+    static constexpr int waves = GS * GT;
+    static constexpr int pairs = (x_rows + t_rows) / 2; // DMA instructions per half-body
+    static constexpr int pairs_per_wave = (pairs + waves - 1) / waves;
+};
+
+struct Stage12mTaps {
+    float h1[17];
+    float h2[19];
+};
+
+template <int GS, int GT>
+__global__ __launch_bounds__(64 * GS * GT, 2)
+void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
+                const Stage12Args a, const PairArgs pa, const Stage12mTaps taps)
+{
+    using G = TileGeomM<GS, GT>;
+    constexpr int SB = 100, Y2B = 4, SPW = 16;
+    constexpr int RB = G::row_bytes;
+    extern __shared__ __attribute__((aligned(16))) char lds_m[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = lane & 15, hi = lane >> 4;
+    const int sg = wave / GT, tg = wave - sg * GT;          // this wave's slot group / segment group inside the workgroup
+
+    // blockIdx -> (slot-group set, time-wave): as k_stage12, the time-waves of one set share blockIdx % 8 (one XCD's L2)
+    const int xcd = blockIdx.x & 7;
+    const int qq = blockIdx.x >> 3;
+    const int wtm = qq % a.n_wt;                            // a.n_wt here: time-waves of GT segment groups
+    const int cgm = a.cg0 + (qq / a.n_wt) * 8 + xcd;        // set of GS slot groups
+    if (cgm >= a.n_chgroups) return;
+    const int gq = wtm / a.P, p = wtm - gq * a.P;
+    const int bps = a.nb * a.P;
+    const int g_first = gq * GT;                            // first segment group of the workgroup
+    if ((g_first * SPW * bps + a.nb * p) * Y2B >= a.n_y2_new) return;
+
+    // ---- what this lane stores: slots 4*hi + r of the wave's group, both channels of each.  A place without channel
+    // (empty slot, no partner) stores into the spare row behind the last channel's: no branch around any store ----
+    const int slot_base = (cgm * GS + sg) * 16;
+    uint32_t yrow[8];                                       // [2 r + (0: channel A, 1: channel B)]: first element of the channel's scratch row
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int s = slot_base + 4 * hi + r;
+        const int2 sl = s < pa.n_slots ? pa.slots[s] : make_int2(-1, -1);
+        const int ca = sl.x >= 0 ? sl.x : a.n_ch, cb = (sl.x >= 0 && sl.y >= 0) ? sl.y : a.n_ch;
+        yrow[2 * r] = (uint32_t)ca * (uint32_t)a.y2_stride;
+        yrow[2 * r + 1] = (uint32_t)cb * (uint32_t)a.y2_stride;
+    }
+    const int g_mine = g_first + tg;                        // this wave's segment group
+    const int wt = g_mine * a.P + p;                        // its time-wave in k_stage12's numbering (scratch layout)
+    const bool seg_live = (g_mine * SPW * bps + a.nb * p) * Y2B < a.n_y2_new;
+
+    // ---- LDS-DMA duties of this wave: pairs wave, wave + waves, ... of the workgroup's row pairs ----
+    // lanes 0..32 move row 2k (33 pieces: the 31 of the row and the 2 of its pad), lanes 33..63 row 2k+1 (31 pieces)
+    const int piece = lane < G::pieces_a ? lane : lane - G::pieces_a;
+    const int rsel = lane < G::pieces_a ? 0 : 1;
+    // (rows of segments past the last segment group that holds data re-read its last segment: inside the ring)
+    const int seg_max = ((a.n_y2_new + Y2B - 1) / Y2B + SPW * bps - 1) / (SPW * bps) * SPW - 1;
+    uint32_t dma_off[G::pairs_per_wave];                    // per-lane byte offset from the pair's wave-uniform base
+    int dma_is_t[G::pairs_per_wave];
+#pragma unroll
+    for (int i = 0; i < G::pairs_per_wave; i++) {
+        const int k = wave + i * G::waves;
+        const int row = 2 * k + rsel;
+        dma_is_t[i] = (2 * k >= G::x_rows);
+        if (2 * k < G::x_rows) {
+            const int seg = min((g_first + row / 16) * SPW + (row & 15), seg_max);
+            dma_off[i] = (uint32_t)(((long long)seg * bps + a.nb * p) * SB * 8 + piece * 16);
+        } else {
+            const int s = cgm * GS * 16 + (row - G::x_rows);
+            int c = s < pa.n_slots ? pa.slots[s].x : -1;
+            if (c < 0) c = 0;                               // an empty slot works on channel 0's table and stores nothing
+            dma_off[i] = (uint32_t)((size_t)c * a.tbl_stride * 8 + piece * 16);
+        }
+    }
+    int tph = a.tphase0 + p * a.nb * SB - G::HALO;          // translator index of the first entry of half-body 0's rows
+    tph %= a.N;
+    if (tph < 0) tph += a.N;
+    const char *xsrc0 = reinterpret_cast<const char *>(x_in + a.x_base - G::HALO);
+    const char *tsrc0 = reinterpret_cast<const char *>(tables);
+    auto issue_half = [&](int hb, int bi, int tphh) {
+        char *buf = lds_m + bi * G::buf_bytes;
+#pragma unroll
+        for (int i = 0; i < G::pairs_per_wave; i++) {
+            const int k = wave + i * G::waves;
+            if (k < G::pairs) {
+                const char *base = dma_is_t[i] ? tsrc0 + (size_t)tphh * 8 : xsrc0 + (size_t)hb * G::HB * 8;
+                __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(base + dma_off[i]), (lds_void *)(uint32_t)(uintptr_t)(buf + 2 * k * RB), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- operand addresses (byte offsets inside a buffer) ----
+    const int aoff = (G::x_rows + sg * 16 + lo) * RB + hi * 8;   // A: t[slot lo][5p + 4j + hi]
+    const int boff = (tg * 16 + lo) * RB + hi * 8;               // B: x[segment lo][5p + 4j + hi]
+    const int doff = (G::x_rows + sg * 16 + 4 * hi) * RB;        // tap 16, C/D layout: t[slot 4 hi + r][5p + 16]
+    const int eoff = (tg * 16 + lo) * RB;                        //                     x[segment lo][5p + 16]
+    v2f hA[4];                                                   // taps 4j + hi, j = 0..3, as (h, h) pairs
+#pragma unroll
+    for (int j = 0; j < 4; j++) hA[j] = v2f{taps.h1[4 * j + hi], taps.h1[4 * j + hi]};
+    const float h16 = taps.h1[16];
+
+    // All vector arithmetic below is written in packed form (v_pk_mul/add/fma_f32 on register pairs): the f32 MFMA and
+    // the vector ALU do not overlap (measured), so beside MFMAs a wave's vector instructions issue alone, at
+    // 4 cycles each whether packed or not.
+    struct Ops { v2f t[4], x[4], tr16[2], ti16[2], x16; };
+    struct Acc { v4f Pr, Pi, Qr, Qi; };
+    Ops ops;
+    Acc acc;
+    // stage-2 accumulators: output (s + dd) & 3 of super-step s; 8 packed values over the lane's slots r = (0,1) and (2,3):
+    // [0,1] re of channel A, [2,3] im of A, [4,5] re of channel B, [6,7] im of B
+    v2f acc2[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc2[q][i] = v2f{0.f, 0.f};
+
+    // (volatile: the operand reads stay single ds_read_b64 -- 32 lanes per LDS cycle on 64 banks, which the row pitch makes
+    // conflict-free; merged into ds_read2_b64 they are served 16 lanes at a time on 32 banks: half the rate, and two-way conflicts)
+    // LDS pointers in their own address space: every operand address is one per-lane base register + an immediate
+    typedef const volatile __attribute__((address_space(3))) v2f lds_cv2f;
+    typedef const __attribute__((address_space(3))) float lds_cf;
+    typedef const __attribute__((address_space(3))) char lds_cc;
+    lds_cc *const lbase = (lds_cc *)(uint32_t)(uintptr_t)lds_m;
+    lds_cc *const la = lbase + aoff, *const lb = lbase + boff, *const ld = lbase + doff, *const le = lbase + eoff;
+    auto load_ops = [&](int bi, int ph, Ops &o) {                // bi: buffer; ph: phase inside the half-body, 0..9
+        const int bo = bi * G::buf_bytes;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            o.t[j] = *(lds_cv2f *)(la + bo + (5 * ph + 4 * j) * 8);
+            o.x[j] = *(lds_cv2f *)(lb + bo + (5 * ph + 4 * j) * 8);
+        }
+        o.x16 = *(lds_cv2f *)(le + bo + (5 * ph + 16) * 8);
+        // tap 16 of slots (4 hi, 4 hi + 1) and (4 hi + 2, 4 hi + 3): real parts together, imaginary parts together (ds_read2_b32)
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            lds_cf *r0 = (lds_cf *)(ld + bo + (2 * rr) * RB + (5 * ph + 16) * 8);
+            lds_cf *r1 = (lds_cf *)(ld + bo + (2 * rr + 1) * RB + (5 * ph + 16) * 8);
+            o.tr16[rr] = v2f{r0[0], r1[0]};
+            o.ti16[rr] = v2f{r0[1], r1[1]};
+        }
+    };
+    auto mfma_phase = [&](const Ops &o, Acc &c) {
+        const v2f xh = o.x16 * v2f{h16, h16};
+        const v2f xr = v2f{xh.x, xh.x}, xi = v2f{xh.y, xh.y};
+        const v2f pr0 = o.tr16[0] * xr, pr1 = o.tr16[1] * xr, pi0 = o.tr16[0] * xi, pi1 = o.tr16[1] * xi;
+        const v2f qr0 = o.ti16[0] * xr, qr1 = o.ti16[1] * xr, qi0 = o.ti16[0] * xi, qi1 = o.ti16[1] * xi;
+        c.Pr = v4f{pr0.x, pr0.y, pr1.x, pr1.y};
+        c.Pi = v4f{pi0.x, pi0.y, pi1.x, pi1.y};
+        c.Qr = v4f{qr0.x, qr0.y, qr1.x, qr1.y};
+        c.Qi = v4f{qi0.x, qi0.y, qi1.x, qi1.y};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const v2f t = o.t[j] * hA[j];
+            const v2f x = o.x[j];
+            c.Pr = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, x.x, c.Pr, 0, 0, 0);
+            c.Pi = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, x.y, c.Pi, 0, 0, 0);
+            c.Qr = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, x.x, c.Qr, 0, 0, 0);
+            c.Qi = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, x.y, c.Qi, 0, 0, 0);
+        }
+    };
+
+    // The two stage-2 outputs a half-body completes wait in `stage` and leave right after the NEXT barrier, as one
+    // 16-byte store per channel (outputs 2 h, 2 h + 1 of the body are neighbours in the body-major scratch): by the
+    // time the following s_waitcnt vmcnt(0) comes they are a whole half-body old.  (Stored where they complete, they
+    // made every barrier wait for a store round trip: 0.85 against 0.64 ms for the launch.)
+    v2f stage[2][8];
+    const uint32_t ylane = (uint32_t)a.y2_hist + ((uint32_t)wt * a.nb * SPW + lo) * Y2B;
+    auto store_staged = [&](int body, int h) {
+        if (body < 0 || !seg_live) return;
+        const uint32_t at = ylane + (uint32_t)body * SPW * Y2B + 2 * h;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            *reinterpret_cast<v4f *>(y2_out + (size_t)(yrow[2 * r] + at)) =
+                v4f{stage[0][r >> 1][r & 1], stage[0][2 + (r >> 1)][r & 1], stage[1][r >> 1][r & 1], stage[1][2 + (r >> 1)][r & 1]};
+            *reinterpret_cast<v4f *>(y2_out + (size_t)(yrow[2 * r + 1] + at)) =
+                v4f{stage[0][4 + (r >> 1)][r & 1], stage[0][6 + (r >> 1)][r & 1], stage[1][4 + (r >> 1)][r & 1], stage[1][6 + (r >> 1)][r & 1]};
+        }
+    };
+    // combinations + stage 2 for stage-1 output P20 (0..19) of a body
+    auto post = [&](auto p20_tag, const Acc &c) {
+        constexpr int P20 = decltype(p20_tag)::value;
+        v2f Y[8];
+        const v2f pr0 = v2f{c.Pr[0], c.Pr[1]}, pr1 = v2f{c.Pr[2], c.Pr[3]}, pi0 = v2f{c.Pi[0], c.Pi[1]}, pi1 = v2f{c.Pi[2], c.Pi[3]};
+        const v2f qr0 = v2f{c.Qr[0], c.Qr[1]}, qr1 = v2f{c.Qr[2], c.Qr[3]}, qi0 = v2f{c.Qi[0], c.Qi[1]}, qi1 = v2f{c.Qi[2], c.Qi[3]};
+        Y[0] = pr0 - qi0;        // channel A = the slot's own table: (Pr - Qi) + j (Pi + Qr)
+        Y[1] = pr1 - qi1;
+        Y[2] = pi0 + qr0;
+        Y[3] = pi1 + qr1;
+        Y[4] = pr0 + qi0;        // channel B = its conjugate:        (Pr + Qi) + j (Pi - Qr)
+        Y[5] = pr1 + qi1;
+        Y[6] = pi0 - qr0;
+        Y[7] = pi1 - qr1;
+        // stage-2 output j (absolute) has the stage-1 outputs 5j-14 .. 5j+4 as its window (S::addSample fires on every
+        // 5th input, msd.hpp:228-247).  Inside a body, input u = P20 % 5 of super-step s = P20 / 5 is element 14 + u - 5 dd
+        // of the window of output s + dd: output s + 3 starts at u = 1 (element 0), output s completes at u = 4 (element 18)
+        constexpr int u = P20 % 5, s = P20 / 5;
+#pragma unroll
+        for (int dd = 0; dd < 4; dd++) {
+            const int e = 14 + u - 5 * dd;
+            if (e < 0) continue;
+            const v2f h = v2f{taps.h2[e], taps.h2[e]};
+            const int slot = (s + dd) & 3;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (e == 0) acc2[slot][i] = Y[i] * h;
+                else acc2[slot][i] = __builtin_elementwise_fma(Y[i], h, acc2[slot][i]);
+            }
+            // pin the updates here: LLVM otherwise sinks every chain down to its store, five phases later, and keeps
+            // all the stage-1 outputs of those phases alive meanwhile (spills)
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("" : "+v"(acc2[slot][i]));
+        }
+        if constexpr (u == 4) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) stage[s & 1][i] = acc2[s & 3][i];
+        }
+    };
+
+    const int n_bodies = 1 + a.nb;                              // one warm-up body
+    issue_half(0, 0, tph);
+    for (int b = 0; b < n_bodies; b++) {
+        const int body = b - 1;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            // this half-body's rows have landed (own DMAs: vmcnt; everybody's: barrier); the barrier also says
+            // every wave is done with the other buffer, which the next half-body's rows may now overwrite
+            const int hb = 2 * b + half;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            tph += G::HB;
+            if (tph >= a.N) tph -= a.N;
+            if (hb + 1 < 2 * n_bodies) issue_half(hb + 1, (half + 1) & 1, tph);
+            // the outputs the previous half-body completed
+            if (half == 0) store_staged(body - 1, 1);
+            else store_staged(body, 0);
+            // the ten phases: phase ph goes to the matrix pipe, the operands of phase ph+1 are fetched into the registers
+            // the MFMAs have just read, then phase ph is finished on the vector pipe (the fetch covers the MFMA latency)
+            auto window = [&](auto ph_tag) {
+                constexpr int P20 = decltype(ph_tag)::value;   // phase inside the body
+                constexpr int ph = P20 % 10;                   // ... inside the half-body
+                mfma_phase(ops, acc);
+                if constexpr (ph + 1 < 10) load_ops(P20 / 10, ph + 1, ops);
+                post(std::integral_constant<int, P20>{}, acc);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto run_half = [&](auto h_tag) {
+                constexpr int H = decltype(h_tag)::value;
+                load_ops(H, 0, ops);
+                window(std::integral_constant<int, H * 10 + 0>{});
+                window(std::integral_constant<int, H * 10 + 1>{});
+                window(std::integral_constant<int, H * 10 + 2>{});
+                window(std::integral_constant<int, H * 10 + 3>{});
+                window(std::integral_constant<int, H * 10 + 4>{});
+                window(std::integral_constant<int, H * 10 + 5>{});
+                window(std::integral_constant<int, H * 10 + 6>{});
+                window(std::integral_constant<int, H * 10 + 7>{});
+                window(std::integral_constant<int, H * 10 + 8>{});
+                window(std::integral_constant<int, H * 10 + 9>{});
+            };
+            if (half == 0) run_half(std::integral_constant<int, 0>{});
+            else run_half(std::integral_constant<int, 1>{});
+        }
+    }
+    store_staged(a.nb - 1, 1);                                  // the last half-body's outputs
+}
+
+}   // namespace sdrxgpu

@@ -3,6 +3,7 @@
 // goes through the HIP kernels or the call fails.
 #include "../../include/sdrx_gpu.h"
 #include "kernels.hpp"
+#include "kernels_mfma.hpp"
 
 #include <algorithm>
 #include <complex>
@@ -289,6 +290,46 @@ static hipError_t k12p_set_attributes()
     return e;
 }
 
+// mixer + stage 1 on the f32 matrix pipe (k_stage12m, kernels_mfma.hpp): 10 MS/s chain; workgroup = GS x GT tiles
+struct K12mLaunch {
+    K12Launch L;
+    PairArgs pa;
+    int GS, GT;
+};
+
+static bool k12m_geometry_compiled(int GS, int GT) { return (GS == 2 && GT == 2) || (GS == 4 && GT == 2) || (GS == 2 && GT == 4); }
+static size_t k12m_lds_bytes(int GS, int GT) { return 2 * (size_t)(16 * GS + 16 * GT) * 528; }
+
+template <int GS, int GT>
+static hipError_t launch_k12m_one(const K12mLaunch &M, const Stage12mTaps &taps, hipStream_t s)
+{
+    static_assert(2 * TileGeomM<GS, GT>::buf_bytes <= 160 * 1024, "two tile buffers must fit the LDS");
+    using TG = TileGeomM<GS, GT>;
+    hipLaunchKernelGGL((k_stage12m<GS, GT>), dim3(M.L.grid), dim3(64 * GS * GT), 2 * TG::buf_bytes, s,
+                       M.L.x, M.L.tables, M.L.y2, M.L.args, M.pa, taps);
+    return hipGetLastError();
+}
+
+static hipError_t launch_k12m(const K12mLaunch &M, hipStream_t s)
+{
+    Stage12mTaps taps{};
+    for (int i = 0; i < 17; i++) taps.h1[i] = M.L.h1[i < 9 ? i : 16 - i];     // (the reference reads h[0 .. half] only, msd.hpp:309-331)
+    for (int i = 0; i < 19; i++) taps.h2[i] = M.L.h2[i < 10 ? i : 18 - i];
+    if (M.GS == 2 && M.GT == 2) return launch_k12m_one<2, 2>(M, taps, s);
+    if (M.GS == 4 && M.GT == 2) return launch_k12m_one<4, 2>(M, taps, s);
+    if (M.GS == 2 && M.GT == 4) return launch_k12m_one<2, 4>(M, taps, s);
+    return hipErrorInvalidValue;
+}
+
+static hipError_t k12m_set_attributes(int GS, int GT)
+{
+    const int n = (int)k12m_lds_bytes(GS, GT);
+    if (GS == 2 && GT == 2) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    if (GS == 4 && GT == 2) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    if (GS == 2 && GT == 4) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    return hipErrorInvalidValue;
+}
+
 struct K12Entry {
     int M1, T1, M2, T2, Y2B;
     int level;
@@ -412,6 +453,13 @@ struct sdrxgpu_bank {
     // beside the kernels of the second; sdrxgpu_bank_process_pinned: H2D of block k+1 beside the kernels of block k)
     // two channels per lane (k_stage12p): slot lists {channel A, channel B or -1; A = -1: empty}, ordered by host part,
     // every part's share padded to whole workgroups of kPairSlots slots
+    // mixer + stage 1 on the f32 matrix pipe (k_stage12m): slot list {channel, its conjugate partner or -1; {-1,-1}: empty},
+    // ordered by host part, every part's share padded to whole workgroup sets of 16 * mGS slots
+    bool mfma = false;
+    int mGS = 2, mGT = 2;
+    int2 *d_slots_m = nullptr;
+    int n_slots_m = 0, n_pairs_m = 0;
+    std::vector<int> part_gm;                         // set boundaries of the host parts
     bool pair = false, want_pair = false;
     int2 *d_slots = nullptr;
     unsigned char *d_group_conj = nullptr;            // per slot group: conjugate partners (one translator row per slot) or any two channels
@@ -485,6 +533,7 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_hist3);
     (void)hipFree(b->d_seam);
     (void)hipFree(b->d_slots);
+    (void)hipFree(b->d_slots_m);
     (void)hipFree(b->d_group_conj);
     (void)hipFree(b->d_keep);
     (void)hipFree(b->d_audio_keep);
@@ -637,6 +686,32 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     const int halo = k12->M1 * (k12->T2 - k12->M2) + (k12->T1 - k12->M1);
     b->WU = (halo + b->SB - 1) / b->SB;
     b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
+    // Mixer + stage 1 on the f32 matrix pipe (k_stage12m): the 10 MS/s chain with translator tables, banks of
+    // 1 024 channels or more unless tuning says otherwise.  Its input rows start T1 - M1 samples in front of a body.
+    const sdrxgpu_tuning tune0 = cfg->tuning ? *cfg->tuning : sdrxgpu_tuning{};
+    {
+        const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && N > 0 && (N % 2) == 0 &&
+                         !b->pipelined;
+        if (tune0.matrix_pipe > 2) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe %u (0..2)", tune0.matrix_pipe);
+        }
+        if (tune0.matrix_pipe == 2 && !can) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = 2, but k_stage12m is built for the 10 MS/s chain "
+                        "(stages (5,17)(5,19)) with translator tables of even length, not pipelined");
+        }
+        b->mfma = can && (tune0.matrix_pipe == 2 || (tune0.matrix_pipe == 0 && b->n_ch >= 1024));
+        if (b->mfma) {
+            b->mGS = tune0.m_slot_groups ? (int)tune0.m_slot_groups : 2;
+            b->mGT = tune0.m_seg_groups ? (int)tune0.m_seg_groups : 2;
+            if (!k12m_geometry_compiled(b->mGS, b->mGT)) {
+                free_bank(b);
+                return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: k_stage12m is not compiled for %d x %d tiles per workgroup", b->mGS, b->mGT);
+            }
+            b->HIST = ((b->WU * b->SB + b->MM + (k12->T1 - k12->M1) + 7) / 8) * 8;
+        }
+    }
     b->Neff = N ? (int)N : b->SB * 12;
     // lane spacing: smallest multiple of the table length that holds a whole number of bodies
     b->spacing = (int)((long long)b->Neff / gcd_ll(b->Neff, b->SB) * b->SB);
@@ -746,6 +821,10 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         }
         if (tune.k12_waves) b->W = (int)tune.k12_waves;
         if (tune.k12_cpw) b->CPW = (int)tune.k12_cpw;
+        if (b->mfma) {          // segments in groups of 16 (the MFMA's N): the scratch layout of W = 4, CPW = 4
+            b->W = 4;
+            b->CPW = 4;
+        }
         if (!k12_geometry_compiled(k12->level, b->W, b->CPW) ||
             2 * (size_t)(kWave / b->CPW + b->W * b->CPW) * (b->SB * 8 + 16) > 160 * 1024) {
             free_bank(b);
@@ -769,6 +848,24 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             for (int nb = b->bps; nb >= 1; nb--) {
                 if (b->bps % nb) continue;
                 const long long wgs = cgs * G * (b->bps / nb);
+                const long long full = wgs / slots, rem = wgs % slots;
+                const double rounds = (double)full + (rem == 0 ? 0.0 : (2 * rem <= slots ? 0.61 : 1.0));
+                const double cost = rounds * (b->WU + nb);
+                if (best_cost < 0 || cost < best_cost * 0.99) {
+                    best_cost = cost;
+                    b->nb = nb;
+                }
+            }
+        }
+        if (b->mfma) {
+            // workgroups of mGS x mGT tiles, two (256 threads) or one (512) per CU; same count of rounds x bodies as above
+            const long long Gs = (U + 16LL * b->bps - 1) / (16LL * b->bps);
+            const long long sets = ((long long)b->n_ch / 2 + 16 * b->mGS - 1) / (16 * b->mGS) + 1;
+            const long long slots = (long long)n_cu * std::max<long long>(1, (long long)(160 * 1024 / k12m_lds_bytes(b->mGS, b->mGT)));
+            double best_cost = -1.0;
+            for (int nb = b->bps; nb >= 1; nb--) {
+                if (b->bps % nb) continue;
+                const long long wgs = sets * ((Gs + b->mGT - 1) / b->mGT) * (b->bps / nb);
                 const long long full = wgs / slots, rem = wgs % slots;
                 const double rounds = (double)full + (rem == 0 ? 0.0 : (2 * rem <= slots ? 0.61 : 1.0));
                 const double cost = rounds * (b->WU + nb);
@@ -803,7 +900,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         const size_t t4_lds = ((size_t)((k12->TB - 1 + 15) / 16) * 16 + max_y3 + 2) * sizeof(float2);   // k_tail4: [hist3 | y3] of one channel
         const bool can = k12->fn_fused && cfg->n_stages == 4 && (int)b->m[2] == k12->MA && (int)b->ntaps[2] == k12->TA &&
                          (int)b->m[3] == k12->MB && (int)b->ntaps[3] == k12->TB && b->P == 1 && !b->pipelined &&
-                         epilogue_row <= lds && n_bnd_max <= 64 && !b->tail_generic && t4_lds <= 64 * 1024;
+                         epilogue_row <= lds && n_bnd_max <= 64 && !b->tail_generic && t4_lds <= 64 * 1024 && !b->mfma;
         if (tune.fused_tail == 2 && !can) {
             free_bank(b);
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.fused_tail = 2, but this bank cannot run stage 3 fused "
@@ -845,7 +942,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         // (fused: the waves of a workgroup read their channels' ranges back into LDS rows of their own, one row at least)
         const size_t epilogue_row = ((size_t)(kWave / b->CPW) * b->bps * k12->Y2B / 2 + kWave - 1) / kWave * kWave * 16;
         const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && b->W == kPairW &&
-                         b->CPW == kPairCPW && !b->pipelined && N > 0 &&
+                         b->CPW == kPairCPW && !b->pipelined && N > 0 && !b->mfma &&
                          (!b->fused || (k12->MA == 5 && k12->TA == 21 && epilogue_row <= k12p_lds_bytes()));
         if (tune.pair_lanes == 2 && !can) {
             free_bank(b);
@@ -916,6 +1013,59 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         }
     }
 
+    if (b->mfma) {
+        // Slots of k_stage12m: a channel and the channel whose table is its exact complex conjugate (+k / -k steps from the
+        // tuner), looked for inside each host part; whoever finds no partner gets a slot of its own (the kernel computes
+        // the pair all the same and drops the second half: a channel's bits do not depend on who else is in the bank).
+        std::vector<int2> slots;
+        const int set = 16 * b->mGS;
+        b->part_gm.assign(1, 0);
+        b->n_pairs_m = 0;
+        auto key_of = [&](uint32_t c, bool flip) {
+            const sdrxgpu_channel &ch = cfg->channels[c];
+            if (ch.n_translator == 0) return std::string("unit");         // no translator = the unit table, its own conjugate
+            std::string k((const char *)ch.translator, (size_t)ch.n_translator * sizeof(sdrxgpu_iq));
+            if (flip)
+                for (size_t i = 0; i < ch.n_translator; i++) k[i * 8 + 7] ^= (char)0x80;   // sign bit of .im
+            return k;
+        };
+        for (size_t p = 0; p + 1 < b->part_ch.size(); p++) {
+            std::unordered_map<std::string, std::vector<int>> open;
+            std::vector<int2> conj;
+            std::vector<int> single;
+            for (int c = b->part_ch[p]; c < b->part_ch[p + 1]; c++) {
+                auto it = open.find(key_of((uint32_t)c, true));
+                if (it != open.end() && !it->second.empty()) {
+                    conj.push_back(make_int2(it->second.back(), c));
+                    it->second.pop_back();
+                } else {
+                    open[key_of((uint32_t)c, false)].push_back(c);
+                }
+            }
+            for (auto &kv : open)
+                for (int c : kv.second) single.push_back(c);
+            std::sort(single.begin(), single.end());
+            std::sort(conj.begin(), conj.end(), [](const int2 &u, const int2 &v) { return u.x < v.x; });
+            b->n_pairs_m += (int)conj.size();
+            slots.insert(slots.end(), conj.begin(), conj.end());
+            for (int c : single) slots.push_back(make_int2(c, -1));
+            while (slots.size() % set) slots.push_back(make_int2(-1, -1));
+            b->part_gm.push_back((int)(slots.size() / set));
+        }
+        b->n_slots_m = (int)slots.size();
+        int rc2;
+        if ((rc2 = dev_alloc(b, (void **)&b->d_slots_m, slots.size() * sizeof(int2)))) {
+            free_bank(b);
+            return rc2;
+        }
+        hipError_t e = hipMemcpy(b->d_slots_m, slots.data(), slots.size() * sizeof(int2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = k12m_set_attributes(b->mGS, b->mGT);
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "k_stage12m set-up failed: %s", hipGetErrorString(e));
+        }
+    }
+
     if (cfg->stream) {
         b->stream = (hipStream_t)cfg->stream;
     } else {
@@ -941,7 +1091,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     if ((rc = dev_alloc(b, (void **)&b->d_xr[0], b->x_capacity * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_xr[1], b->x_capacity * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_tables, 2 * (size_t)b->n_ch * b->tbl_stride * sizeof(float2))) ||
-        (rc = dev_alloc(b, (void **)&b->d_y2, (size_t)b->n_ch * b->y2_stride * sizeof(float2))) ||
+        (rc = dev_alloc(b, (void **)&b->d_y2, ((size_t)b->n_ch + (b->mfma ? 1 : 0)) * b->y2_stride * sizeof(float2))) ||   // (k_stage12m: a spare row for places without channel)
         (b->pipelined && (rc = dev_alloc(b, (void **)&b->d_y2b, (size_t)b->n_ch * b->y2_stride * sizeof(float2)))) ||
         (!b->fused && (rc = dev_alloc(b, (void **)&b->d_hist[0], (size_t)b->n_ch * b->y2_hist * sizeof(float2)))) ||
         (!b->fused && (rc = dev_alloc(b, (void **)&b->d_hist[1], (size_t)b->n_ch * b->y2_hist * sizeof(float2)))) ||
@@ -1172,6 +1322,8 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
     info->k12_waves = (uint32_t)b->W;
     info->k12_cpw = (uint32_t)b->CPW;
     info->k12_bodies = (uint32_t)b->nb;
+    info->matrix_pipe = b->mfma ? 1u : 0u;
+    info->m_slots = b->mfma ? (uint32_t)b->n_slots_m : 0u;
     return SDRXGPU_OK;
 }
 
@@ -1331,6 +1483,29 @@ static int launch_k12_range(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
 // Launch the stage-1/2 kernel of a prepared chunk for the host parts [p_lo, p_hi) (all of them: the whole bank).
 static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStream_t st, int p_lo, int p_hi)
 {
+    if (b->mfma) {
+        ProfScope ps(b, SDRXGPU_K_STAGE12, st);
+        const int g_lo = b->part_gm[p_lo], g_hi = b->part_gm[p_hi];
+        if (g_hi <= g_lo) return SDRXGPU_OK;
+        K12mLaunch M;
+        M.L = job->L;
+        M.GS = b->mGS;
+        M.GT = b->mGT;
+        const int Gs = M.L.args.n_wt / b->P;                            // segment groups of the call
+        M.L.args.n_wt = (Gs + b->mGT - 1) / b->mGT * b->P;              // time-waves of mGT segment groups
+        M.L.args.cg0 = g_lo;
+        M.L.args.n_chgroups = g_hi;
+        M.L.args.n_cgx = (g_hi - g_lo + 7) / 8 * 8;
+        M.L.grid = M.L.args.n_cgx * M.L.args.n_wt;
+        M.pa.slots = b->d_slots_m;
+        M.pa.group_conj = nullptr;
+        M.pa.n_slots = b->n_slots_m;
+        M.pa.lds_bytes = (int)k12m_lds_bytes(b->mGS, b->mGT);
+        if ((uint64_t)(b->n_ch + 1) * (uint64_t)b->y2_stride >= (1ull << 32))
+            return fail(SDRXGPU_ERR_HIP, "internal: stage-2 scratch of %u x %d entries exceeds k_stage12m's 32-bit row offsets", b->n_ch, b->y2_stride);
+        HIPCHK(launch_k12m(M, st));
+        return SDRXGPU_OK;
+    }
     if (!b->pair) {
         const int gsz = b->W * b->CPW;
         return launch_k12_range(b, job, st, b->part_ch[p_lo] / gsz, (b->part_ch[p_hi] + gsz - 1) / gsz);
@@ -1410,6 +1585,8 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         a.n_cgx = (a.n_chgroups + 7) / 8 * 8;
         if (a.x_base < 0 || (a.x_base & 1) || (a.tphase0 & 1))
             return fail(SDRXGPU_ERR_HIP, "internal: x_base %d / tphase0 %d must be even and >= 0", a.x_base, a.tphase0);
+        if (b->mfma && a.x_base < k->T1 - k->M1)
+            return fail(SDRXGPU_ERR_HIP, "internal: x_base %d leaves no room for k_stage12m's %d samples of row history", a.x_base, k->T1 - k->M1);
         const size_t x_need = (size_t)a.x_base + (size_t)G * SPW * b->spacing + (size_t)(b->WU + 1) * b->SB;
         if (x_need > b->x_capacity) return fail(SDRXGPU_ERR_HIP, "internal: input ring too small (%zu > %zu)", x_need, b->x_capacity);
         L.h1 = b->taps[0].data();

@@ -1,0 +1,181 @@
+"""Mixer + stage 1 of the 10 MS/s chain on the f32 matrix pipe (k_stage12m): the same channel outputs as the vector
+kernels up to fp32 rounding (another summation order: the reference's own AVX2 and portable builds differ likewise), so
+this path is held to the oracle at north_star's 1e-5 -- and to ITSELF bit for bit wherever the reference is
+deterministic: however the stream is cut into calls, whatever the workgroup shape or the lane length, whoever else is
+in the bank (a channel's partner, repeated instances), host entry or device entry."""
+import numpy as np
+import pytest
+
+from conftest import RTOL, rel_err_rows, margin
+from sdrx_amd import bank as sb, chains, synth
+
+pytestmark = pytest.mark.gpu
+
+WHOLE = 0xFFFFFFFF
+OFF, REQ = 1, 2
+
+
+def _run(ch, tabs, blocks, tuning=None, block_hint=0, **kw):
+    t = {"matrix_pipe": REQ}
+    t.update(tuning or {})
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=block_hint, tuning=t, **kw)
+    info = bank.info()
+    outs = [bank.process(x) for x in blocks]
+    bank.close()
+    return np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1), info
+
+
+def _cut(stream, lens):
+    out, p = [], 0
+    for n in lens:
+        n = min(n, len(stream) - p)
+        out.append(stream[p:p + n])
+        p += n
+    assert p == len(stream)
+    return out
+
+
+def _oracle(oracle, ch, tabs, blocks, **kw):
+    ob = oracle.bank(tabs, ch.stage_tuples(), **kw)
+    r = [ob.process(x) for x in blocks]
+    return np.concatenate([v[0] for v in r], axis=1), np.concatenate([v[1] for v in r], axis=1)
+
+
+OFFSETS = [
+    list(range(-20, 21)),                                  # 20 conjugate pairs + the untranslated channel
+    [5, -5, 5, -5, 7, 9, 11, 0, 0, -7, 600 - 1200, 13],     # repeated offsets, loners, two untranslated, -600 (its own conjugate)
+    [3],                                                   # a single channel
+    [4, -4],                                               # one pair
+    list(range(1, 38)),                                    # no partners at all
+]
+
+
+@pytest.mark.parametrize("offs", OFFSETS)
+def test_matrix_pipe_matches_the_oracle(oracle, offs):
+    ch = chains.chain("10")
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    stream = synth.synth_iq(31, 0, 2 * L + 4321, 0.25, [t for t in tabs[:1] if t is not None], [0.3], ch.N, 10000)
+    lens = [L, 0, 624, 625, 777, L // 2, 10 ** 9]
+    iq, au, info = _run(ch, tabs, _cut(stream, lens))
+    assert info.matrix_pipe == 1 and info.fused_tail == 0 and info.pair_lanes == 0
+    riq, rau = _oracle(oracle, ch, tabs, _cut(stream, lens))
+    e_iq, e_au = rel_err_rows(iq, riq), rel_err_rows(au, rau)
+    margin("matrix_pipe_vs_oracle_%dch" % len(offs), iq=e_iq, audio=e_au)
+    assert e_iq <= RTOL and e_au <= RTOL
+
+
+def test_matrix_pipe_is_close_to_the_vector_kernels_but_not_equal():
+    ch = chains.chain("10")
+    offs = list(range(-20, 21))
+    tabs = sb.translators_for(ch, offs)
+    blocks = [synth.synth_iq(5, 0, ch.block_len, 0.25, [tabs[3]], [0.3], ch.N, 10000)]
+    m = _run(ch, tabs, blocks)
+    v = _run(ch, tabs, blocks, tuning={"matrix_pipe": OFF})
+    assert v[2].matrix_pipe == 0
+    assert rel_err_rows(m[0], v[0]) <= 5e-6
+    assert not np.array_equal(m[0].view(np.uint32), v[0].view(np.uint32))      # (if this ever fails the two paths have become one)
+
+
+@pytest.mark.parametrize("offs", OFFSETS[:2])
+def test_any_split_of_the_stream_gives_the_same_bits(offs):
+    ch = chains.chain("10")
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    stream = synth.synth_iq(77, 0, 2 * L + 1234, 0.25, [t for t in tabs[:1] if t is not None], [0.3], ch.N, 10000)
+    whole = _run(ch, tabs, _cut(stream, [L, L, 10 ** 9]))
+    for lens in ([L, 0, 624, 625, 777, L // 2, 10 ** 9], [1, 24, 25, 26, 99, 100, 101, 1199, 1200, 1201, 5000, 10 ** 9], [L // 3] * 7):
+        got = _run(ch, tabs, _cut(stream, lens))
+        assert np.array_equal(whole[0].view(np.uint32), got[0].view(np.uint32))
+        assert np.array_equal(whole[1].view(np.uint32), got[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("gs,gt", [(4, 2), (2, 4)])
+def test_workgroup_shapes_and_lane_lengths_give_the_same_bits(gs, gt):
+    ch = chains.chain("10")
+    offs = list(range(-40, 41)) + [0, 7, 7]
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    stream = synth.synth_iq(78, 0, L + 30000, 0.25)
+    lens = [L, 625, 10 ** 9]
+    want = _run(ch, tabs, _cut(stream, lens), block_hint=WHOLE)
+    for hint in (WHOLE, 1, 3, 4):
+        got = _run(ch, tabs, _cut(stream, lens), tuning={"m_slot_groups": gs, "m_seg_groups": gt}, block_hint=hint)
+        assert got[2].k12_bodies == (12 if hint == WHOLE else hint)
+        assert np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32))
+        assert np.array_equal(want[1].view(np.uint32), got[1].view(np.uint32))
+
+
+def test_a_channels_bits_do_not_depend_on_who_else_is_in_the_bank():
+    ch = chains.chain("10")
+    L = ch.block_len
+    stream = [synth.synth_iq(79, 0, L, 0.25)]
+    t = sb.translators_for(ch, [37, -37, 0, 599])
+    # each channel with as little company as a bank allows (the untranslated one needs somebody who fixes the table length)
+    alone = [_run(ch, [t[0]], stream)[0][0], _run(ch, [t[1]], stream)[0][0], _run(ch, [t[3], t[2]], stream)[0][1], _run(ch, [t[3]], stream)[0][0]]
+    both = _run(ch, t, stream)[0]
+    many = _run(ch, t * 9 + [t[0]], stream)[0]
+    swapped = _run(ch, [t[1], t[0]], stream)[0]                  # the partner comes first: roles in the slot are exchanged
+    for i in range(4):
+        assert np.array_equal(alone[i].view(np.uint32), both[i].view(np.uint32))
+        for k in range(9):
+            assert np.array_equal(alone[i].view(np.uint32), many[4 * k + i].view(np.uint32))
+    assert np.array_equal(alone[0].view(np.uint32), many[36].view(np.uint32))
+    assert np.array_equal(alone[0].view(np.uint32), swapped[1].view(np.uint32))
+    assert np.array_equal(alone[1].view(np.uint32), swapped[0].view(np.uint32))
+
+
+def test_large_bank_by_default_host_parts_and_oracle(oracle):
+    ch = chains.chain("10")
+    n_ch = 5000                                            # two host parts, several time tiles, 1 200 distinct offsets
+    offs = chains.offsets_cycled(n_ch, ch.N)
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    blocks = [synth.synth_iq(9, b * L, L, 0.25, [tabs[650]], [0.2], ch.N, 10000) for b in range(2)]
+    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    info = bank.info()
+    assert info.matrix_pipe == 1
+    outs = [bank.process(x) for x in blocks]                # host entry: channel parts, D2H beside the kernels
+    bank.close()
+    iq = np.concatenate([o[0] for o in outs], axis=1)
+    au = np.concatenate([o[1] for o in outs], axis=1)
+    # repeated instances of an offset are computed independently and come out bit-identical
+    for c in range(0, n_ch - ch.N, 97):
+        assert np.array_equal(iq[c].view(np.uint32), iq[c + ch.N].view(np.uint32))
+    worst_iq = worst_au = 0.0
+    for c in (0, 1, 599, 600, 601, 1199, 1200, 2559, 2560, 4999):
+        riq, rau = _oracle(oracle, ch, [tabs[c]], blocks)
+        worst_iq = max(worst_iq, rel_err_rows(iq[c:c + 1], riq))
+        worst_au = max(worst_au, rel_err_rows(au[c:c + 1], rau))
+    margin("matrix_pipe_5000ch_vs_oracle", iq=worst_iq, audio=worst_au)
+    assert worst_iq <= RTOL and worst_au <= RTOL
+
+
+def test_matrix_pipe_with_ftfir_squelch_fm_lf_agc_and_audio_fir(oracle):
+    """Everything around the stage-1/2 kernel is unchanged: --ftfir (tables doubled and phase-shifted: still conjugates of
+    each other), squelch + FM + audio FIR downstream."""
+    ch = chains.chain("10")
+    offs = list(range(-12, 13)) + [300, -300, 7]
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    pb, ru, rd = chains.squelch_tables()
+    on = [False, True, True, False]
+    blocks = [synth.synth_iq(3, b * L, L, 0.25, [tabs[1]] if c else [], [0.25] if c else [], ch.N, 10000) for b, c in enumerate(on)]
+    kw = dict(ftfir=True, squelch=(np.full(len(offs), 6.0, np.float32), pb, ru, rd),
+              modulation=["FM" if i % 5 == 0 else "AM" for i in range(len(offs))], audio_fir=chains.audio_bpf_taps())
+    m = _run(ch, tabs, blocks, **kw)
+    v = _run(ch, tabs, blocks, tuning={"matrix_pipe": OFF}, **kw)
+    e_iq, e_au = rel_err_rows(m[0], v[0]), rel_err_rows(m[1], v[1])
+    margin("matrix_pipe_ftfir_squelch_fm_vs_vector_kernels", iq=e_iq, audio=e_au)
+    assert e_iq <= 5e-6 and e_au <= RTOL
+
+
+def test_matrix_pipe_is_refused_where_it_cannot_run():
+    ch = chains.chain("2.4")
+    with pytest.raises(sb.SdrxGpuError):
+        sb.ChannelBank(sb.translators_for(ch, [1, -1]), ch.stage_tuples(), tuning={"matrix_pipe": REQ})
+    ch = chains.chain("10")
+    with pytest.raises(sb.SdrxGpuError):
+        sb.ChannelBank(sb.translators_for(ch, [1, -1]), ch.stage_tuples(), tuning={"matrix_pipe": REQ, "m_slot_groups": 3, "m_seg_groups": 1})
+    with pytest.raises(sb.SdrxGpuError):
+        sb.ChannelBank([None, None], ch.stage_tuples(), tuning={"matrix_pipe": REQ})        # nobody mixes: no table length to space the segments by
