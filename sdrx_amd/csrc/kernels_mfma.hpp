@@ -50,7 +50,7 @@ struct TileGeomM {
 
 struct Stage12mTaps {
     float h1[17];
-    float h2[19];
+    float h2[10];       // h2[0 .. 9]; h2[18 - e] = h2[e] (the reference reads that half only, msd.hpp:309-331): 10 scalar register pairs, not 19
 };
 
 template <int GS, int GT>
@@ -199,10 +199,14 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         for (int j = 0; j < 4; j++) {
             const v2f t = o.t[j] * hA[j];
             const v2f x = o.x[j];
+#ifndef LAB_NOMFMA
             c.Pr = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, x.x, c.Pr, 0, 0, 0);
             c.Pi = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, x.y, c.Pi, 0, 0, 0);
             c.Qr = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, x.x, c.Qr, 0, 0, 0);
             c.Qi = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, x.y, c.Qi, 0, 0, 0);
+#else
+            c.Pr[j] += t.x * x.x; c.Pi[j] += t.x * x.y; c.Qr[j] += t.y * x.x; c.Qi[j] += t.y * x.y;
+#endif
         }
     };
 
@@ -213,6 +217,9 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     v2f stage[2][8];
     const uint32_t ylane = (uint32_t)a.y2_hist + ((uint32_t)wt * a.nb * SPW + lo) * Y2B;
     auto store_staged = [&](int body, int h) {
+#ifdef LAB_NOSTORE
+        if (a.n_ch > 0) return;
+#endif
         if (body < 0 || !seg_live) return;
         const uint32_t at = ylane + (uint32_t)body * SPW * Y2B + 2 * h;
 #pragma unroll
@@ -241,11 +248,18 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         // 5th input, msd.hpp:228-247).  Inside a body, input u = P20 % 5 of super-step s = P20 / 5 is element 14 + u - 5 dd
         // of the window of output s + dd: output s + 3 starts at u = 1 (element 0), output s completes at u = 4 (element 18)
         constexpr int u = P20 % 5, s = P20 / 5;
+#ifdef LAB_NOPOST
+        if constexpr (u == 4) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc2[s & 3][i] += Y[i];
+        }
+#else
 #pragma unroll
         for (int dd = 0; dd < 4; dd++) {
             const int e = 14 + u - 5 * dd;
             if (e < 0) continue;
-            const v2f h = v2f{taps.h2[e], taps.h2[e]};
+            const float he = taps.h2[e < 10 ? e : 18 - e];
+            const v2f h = v2f{he, he};
             const int slot = (s + dd) & 3;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -257,6 +271,7 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
 #pragma unroll
             for (int i = 0; i < 8; i++) asm volatile("" : "+v"(acc2[slot][i]));
         }
+#endif
         if constexpr (u == 4) {
 #pragma unroll
             for (int i = 0; i < 8; i++) stage[s & 1][i] = acc2[s & 3][i];
@@ -272,11 +287,17 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
             // this half-body's rows have landed (own DMAs: vmcnt; everybody's: barrier); the barrier also says
             // every wave is done with the other buffer, which the next half-body's rows may now overwrite
             const int hb = 2 * b + half;
+#ifdef LAB_NOSYNC
+            if (hb < 2) {
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             tph += G::HB;
             if (tph >= a.N) tph -= a.N;
             if (hb + 1 < 2 * n_bodies) issue_half(hb + 1, (half + 1) & 1, tph);
+#ifdef LAB_NOSYNC
+            }
+#endif
             // the outputs the previous half-body completed
             if (half == 0) store_staged(body - 1, 1);
             else store_staged(body, 0);
@@ -290,22 +311,31 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
                 post(std::integral_constant<int, P20>{}, acc);
                 __builtin_amdgcn_sched_barrier(0);
             };
-            auto run_half = [&](auto h_tag) {
+            // Stage 2's first real output has the stage-1 outputs from phase 6 of the warm-up body on as its window:
+            // phases 0..5 of that body are nobody's input and are skipped.
+            auto run_half = [&](auto h_tag, const bool from6) {
                 constexpr int H = decltype(h_tag)::value;
-                load_ops(H, 0, ops);
-                window(std::integral_constant<int, H * 10 + 0>{});
-                window(std::integral_constant<int, H * 10 + 1>{});
-                window(std::integral_constant<int, H * 10 + 2>{});
-                window(std::integral_constant<int, H * 10 + 3>{});
-                window(std::integral_constant<int, H * 10 + 4>{});
-                window(std::integral_constant<int, H * 10 + 5>{});
+                if (!from6) {
+                    load_ops(H, 0, ops);
+                    window(std::integral_constant<int, H * 10 + 0>{});
+                    window(std::integral_constant<int, H * 10 + 1>{});
+                    window(std::integral_constant<int, H * 10 + 2>{});
+                    window(std::integral_constant<int, H * 10 + 3>{});
+                    window(std::integral_constant<int, H * 10 + 4>{});
+                    window(std::integral_constant<int, H * 10 + 5>{});
+                } else {
+                    load_ops(H, 6, ops);
+                }
                 window(std::integral_constant<int, H * 10 + 6>{});
                 window(std::integral_constant<int, H * 10 + 7>{});
                 window(std::integral_constant<int, H * 10 + 8>{});
                 window(std::integral_constant<int, H * 10 + 9>{});
             };
-            if (half == 0) run_half(std::integral_constant<int, 0>{});
-            else run_half(std::integral_constant<int, 1>{});
+            // (a wave whose segment group lies past the end of the data only keeps the workgroup's barriers and its share of the DMAs)
+            if (seg_live) {
+                if (half == 0) run_half(std::integral_constant<int, 0>{}, b == 0);
+                else run_half(std::integral_constant<int, 1>{}, false);
+            }
         }
     }
     store_staged(a.nb - 1, 1);                                  // the last half-body's outputs

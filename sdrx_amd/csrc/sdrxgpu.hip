@@ -314,7 +314,7 @@ static hipError_t launch_k12m(const K12mLaunch &M, hipStream_t s)
 {
     Stage12mTaps taps{};
     for (int i = 0; i < 17; i++) taps.h1[i] = M.L.h1[i < 9 ? i : 16 - i];     // (the reference reads h[0 .. half] only, msd.hpp:309-331)
-    for (int i = 0; i < 19; i++) taps.h2[i] = M.L.h2[i < 10 ? i : 18 - i];
+    for (int i = 0; i < 10; i++) taps.h2[i] = M.L.h2[i];
     if (M.GS == 2 && M.GT == 2) return launch_k12m_one<2, 2>(M, taps, s);
     if (M.GS == 4 && M.GT == 2) return launch_k12m_one<4, 2>(M, taps, s);
     if (M.GS == 2 && M.GT == 4) return launch_k12m_one<2, 4>(M, taps, s);
@@ -457,8 +457,8 @@ struct sdrxgpu_bank {
     // ordered by host part, every part's share padded to whole workgroup sets of 16 * mGS slots
     bool mfma = false;
     int mGS = 2, mGT = 2;
-    int2 *d_slots_m = nullptr;
-    int n_slots_m = 0, n_pairs_m = 0;
+    int2 *d_slots_m = nullptr, *d_slots_mp = nullptr;  // partners from the whole bank / from inside each host part
+    int n_slots_m = 0, n_slots_mp = 0, n_pairs_m = 0;
     std::vector<int> part_gm;                         // set boundaries of the host parts
     bool pair = false, want_pair = false;
     int2 *d_slots = nullptr;
@@ -701,7 +701,14 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = 2, but k_stage12m is built for the 10 MS/s chain "
                         "(stages (5,17)(5,19)) with translator tables of even length, not pipelined");
         }
-        b->mfma = can && (tune0.matrix_pipe == 2 || (tune0.matrix_pipe == 0 && b->n_ch >= 1024));
+        // (automatic only where nothing else about the stage-1/2 kernel is asked for: a required fused tail, required pair lanes
+        // or a forced geometry mean the vector kernels)
+        const bool others = tune0.fused_tail == 2 || tune0.pair_lanes == 2 || tune0.k12_waves || tune0.k12_cpw;
+        if (tune0.matrix_pipe == 2 && others) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe = 2 goes with neither fused_tail = 2, pair_lanes = 2 nor k12_waves / k12_cpw");
+        }
+        b->mfma = can && (tune0.matrix_pipe == 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 1024));
         if (b->mfma) {
             b->mGS = tune0.m_slot_groups ? (int)tune0.m_slot_groups : 2;
             b->mGT = tune0.m_seg_groups ? (int)tune0.m_seg_groups : 2;
@@ -1015,12 +1022,11 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
 
     if (b->mfma) {
         // Slots of k_stage12m: a channel and the channel whose table is its exact complex conjugate (+k / -k steps from the
-        // tuner), looked for inside each host part; whoever finds no partner gets a slot of its own (the kernel computes
-        // the pair all the same and drops the second half: a channel's bits do not depend on who else is in the bank).
-        std::vector<int2> slots;
+        // tuner); whoever finds no partner gets a slot of its own (the kernel computes the pair all the same and drops the
+        // second half: a channel's bits do not depend on who else is in the bank).  Two lists: partners looked for in the
+        // whole bank (launches that cover every channel: the device and pinned entries), and inside each host part
+        // (sdrxgpu_bank_process runs the parts one after the other, every kernel on one part's channels).
         const int set = 16 * b->mGS;
-        b->part_gm.assign(1, 0);
-        b->n_pairs_m = 0;
         auto key_of = [&](uint32_t c, bool flip) {
             const sdrxgpu_channel &ch = cfg->channels[c];
             if (ch.n_translator == 0) return std::string("unit");         // no translator = the unit table, its own conjugate
@@ -1029,36 +1035,52 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 for (size_t i = 0; i < ch.n_translator; i++) k[i * 8 + 7] ^= (char)0x80;   // sign bit of .im
             return k;
         };
-        for (size_t p = 0; p + 1 < b->part_ch.size(); p++) {
+        std::vector<std::string> keys(b->n_ch), fkeys(b->n_ch);
+        for (uint32_t c = 0; c < b->n_ch; c++) {
+            keys[c] = key_of(c, false);
+            fkeys[c] = key_of(c, true);
+        }
+        auto pair_range = [&](int c_lo, int c_hi, std::vector<int2> &slots, int &n_pairs) {
             std::unordered_map<std::string, std::vector<int>> open;
             std::vector<int2> conj;
             std::vector<int> single;
-            for (int c = b->part_ch[p]; c < b->part_ch[p + 1]; c++) {
-                auto it = open.find(key_of((uint32_t)c, true));
+            for (int c = c_lo; c < c_hi; c++) {
+                auto it = open.find(fkeys[c]);
                 if (it != open.end() && !it->second.empty()) {
                     conj.push_back(make_int2(it->second.back(), c));
                     it->second.pop_back();
                 } else {
-                    open[key_of((uint32_t)c, false)].push_back(c);
+                    open[keys[c]].push_back(c);
                 }
             }
             for (auto &kv : open)
                 for (int c : kv.second) single.push_back(c);
             std::sort(single.begin(), single.end());
             std::sort(conj.begin(), conj.end(), [](const int2 &u, const int2 &v) { return u.x < v.x; });
-            b->n_pairs_m += (int)conj.size();
+            n_pairs += (int)conj.size();
             slots.insert(slots.end(), conj.begin(), conj.end());
             for (int c : single) slots.push_back(make_int2(c, -1));
             while (slots.size() % set) slots.push_back(make_int2(-1, -1));
-            b->part_gm.push_back((int)(slots.size() / set));
+        };
+        std::vector<int2> slots_all, slots_parts;
+        int np_all = 0, np_parts = 0;
+        pair_range(0, (int)b->n_ch, slots_all, np_all);
+        b->part_gm.assign(1, 0);
+        for (size_t p = 0; p + 1 < b->part_ch.size(); p++) {
+            pair_range(b->part_ch[p], b->part_ch[p + 1], slots_parts, np_parts);
+            b->part_gm.push_back((int)(slots_parts.size() / set));
         }
-        b->n_slots_m = (int)slots.size();
+        b->n_pairs_m = np_all;
+        b->n_slots_m = (int)slots_all.size();
+        b->n_slots_mp = (int)slots_parts.size();
         int rc2;
-        if ((rc2 = dev_alloc(b, (void **)&b->d_slots_m, slots.size() * sizeof(int2)))) {
+        if ((rc2 = dev_alloc(b, (void **)&b->d_slots_m, (slots_all.size() + slots_parts.size()) * sizeof(int2)))) {
             free_bank(b);
             return rc2;
         }
-        hipError_t e = hipMemcpy(b->d_slots_m, slots.data(), slots.size() * sizeof(int2), hipMemcpyHostToDevice);
+        b->d_slots_mp = b->d_slots_m + slots_all.size();
+        hipError_t e = hipMemcpy(b->d_slots_m, slots_all.data(), slots_all.size() * sizeof(int2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->d_slots_mp, slots_parts.data(), slots_parts.size() * sizeof(int2), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = k12m_set_attributes(b->mGS, b->mGT);
         if (e != hipSuccess) {
             free_bank(b);
@@ -1485,7 +1507,8 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
 {
     if (b->mfma) {
         ProfScope ps(b, SDRXGPU_K_STAGE12, st);
-        const int g_lo = b->part_gm[p_lo], g_hi = b->part_gm[p_hi];
+        const bool whole = p_lo == 0 && p_hi == (int)b->part_ch.size() - 1;
+        const int g_lo = whole ? 0 : b->part_gm[p_lo], g_hi = whole ? b->n_slots_m / (16 * b->mGS) : b->part_gm[p_hi];
         if (g_hi <= g_lo) return SDRXGPU_OK;
         K12mLaunch M;
         M.L = job->L;
@@ -1497,9 +1520,9 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
         M.L.args.n_chgroups = g_hi;
         M.L.args.n_cgx = (g_hi - g_lo + 7) / 8 * 8;
         M.L.grid = M.L.args.n_cgx * M.L.args.n_wt;
-        M.pa.slots = b->d_slots_m;
+        M.pa.slots = whole ? b->d_slots_m : b->d_slots_mp;
         M.pa.group_conj = nullptr;
-        M.pa.n_slots = b->n_slots_m;
+        M.pa.n_slots = whole ? b->n_slots_m : b->n_slots_mp;
         M.pa.lds_bytes = (int)k12m_lds_bytes(b->mGS, b->mGT);
         if ((uint64_t)(b->n_ch + 1) * (uint64_t)b->y2_stride >= (1ull << 32))
             return fail(SDRXGPU_ERR_HIP, "internal: stage-2 scratch of %u x %d entries exceeds k_stage12m's 32-bit row offsets", b->n_ch, b->y2_stride);

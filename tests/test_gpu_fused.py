@@ -95,7 +95,7 @@ def test_large_bank_automatic_path_matches_the_oracle(oracle):
     tabs = sb.translators_for(ch, offs)
     L = ch.block_len
     blocks = [synth.synth_iq(77, b * L, L, 0.25, [tabs[700]], [0.2], ch.N, 10000) for b in range(2)]
-    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": 1})   # (the vector kernels' automatic path; tests/test_gpu_matrix.py covers the default)
     assert bank.info().pair_lanes > 1000
     iq, au = _run(bank, blocks)
     for c in (0, 1, 599, 600, 700, 1200, 3999):

@@ -71,14 +71,14 @@ def test_large_bank_pairs_by_default_and_matches_the_oracle_and_the_host_parts(o
     tabs = sb.translators_for(ch, offs)
     L = ch.block_len
     blocks = [synth.synth_iq(9, b * L, L, 0.25, [tabs[650]], [0.2], ch.N, 10000) for b in range(2)]
-    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": 1})   # (the vector kernels' automatic path; tests/test_gpu_matrix.py covers the default)
     info = bank.info()
     assert info.pair_lanes > 4000 and info.fused_tail == 1      # (partners are looked for inside a host part: 4 712 of the 4 990 possible)
     outs = [bank.process(x) for x in blocks]                # host entry: channel parts, D2H beside the kernels
     bank.close()
     iq = np.concatenate([o[0] for o in outs], axis=1)
     au = np.concatenate([o[1] for o in outs], axis=1)
-    single = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"pair_lanes": OFF})
+    single = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"pair_lanes": OFF, "matrix_pipe": 1})
     assert single.info().pair_lanes == 0
     o2 = [single.process(x) for x in blocks]
     single.close()
