@@ -47,6 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--matrix", type=int, default=0, help="tuning.matrix_pipe: 0 auto, 1 vector kernels only, 2 require k_stage12m (mixer + stage 1 on the f32 matrix pipe)")
     ap.add_argument("--mgs", type=int, default=0, help="tuning.m_slot_groups (k_stage12m workgroup shape), 0 auto")
     ap.add_argument("--mgt", type=int, default=0, help="tuning.m_seg_groups, 0 auto")
+    ap.add_argument("--tail-tile", type=int, default=0, help="tuning.tail_tile (final outputs per workgroup of the separate tail kernel), 0 auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--pipelined", action="store_true",
@@ -340,8 +341,9 @@ def main():
         ring = torch.from_numpy(host).cuda()
 
     tuning = None
-    if args.fused or args.pair or args.matrix or args.mgs or args.mgt:
-        tuning = {"fused_tail": args.fused, "pair_lanes": args.pair, "matrix_pipe": args.matrix, "m_slot_groups": args.mgs, "m_seg_groups": args.mgt}
+    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile:
+        tuning = {"fused_tail": args.fused, "pair_lanes": args.pair, "matrix_pipe": args.matrix, "m_slot_groups": args.mgs, "m_seg_groups": args.mgt,
+                  "tail_tile": args.tail_tile}
     fused_seen = {}
     pair_seen = {}
     matrix_seen = {}

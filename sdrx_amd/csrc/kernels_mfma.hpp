@@ -69,16 +69,20 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     const int lo = lane & 15, hi = lane >> 4;
     const int sg = wave / GT, tg = wave - sg * GT;          // this wave's slot group / segment group inside the workgroup
 
-    // blockIdx -> (slot-group set, time-wave): as k_stage12, the time-waves of one set share blockIdx % 8 (one XCD's L2)
-    const int xcd = blockIdx.x & 7;
-    const int qq = blockIdx.x >> 3;
+    // A workgroup takes the items blockIdx.x, blockIdx.x + gridDim.x, ... (the host launches one workgroup per item; a smaller
+    // grid makes the workgroups persistent).  item -> (slot-group set, time-wave): as k_stage12, the time-waves of one set
+    // share item % 8 (one XCD's L2 under the round-robin placement of blocks; gridDim.x is a multiple of 8)
+    const int n_items = a.n_cgx * a.n_wt;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int xcd = item & 7;
+    const int qq = item >> 3;
     const int wtm = qq % a.n_wt;                            // a.n_wt here: time-waves of GT segment groups
     const int cgm = a.cg0 + (qq / a.n_wt) * 8 + xcd;        // set of GS slot groups
-    if (cgm >= a.n_chgroups) return;
+    if (cgm >= a.n_chgroups) continue;
     const int gq = wtm / a.P, p = wtm - gq * a.P;
     const int bps = a.nb * a.P;
     const int g_first = gq * GT;                            // first segment group of the workgroup
-    if ((g_first * SPW * bps + a.nb * p) * Y2B >= a.n_y2_new) return;
+    if ((g_first * SPW * bps + a.nb * p) * Y2B >= a.n_y2_new) continue;
 
     // ---- what this lane stores: slots 4*hi + r of the wave's group, both channels of each.  A place without channel
     // (empty slot, no partner) stores into the spare row behind the last channel's: no branch around any store ----
@@ -199,14 +203,10 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         for (int j = 0; j < 4; j++) {
             const v2f t = o.t[j] * hA[j];
             const v2f x = o.x[j];
-#ifndef LAB_NOMFMA
             c.Pr = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, x.x, c.Pr, 0, 0, 0);
             c.Pi = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, x.y, c.Pi, 0, 0, 0);
             c.Qr = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, x.x, c.Qr, 0, 0, 0);
             c.Qi = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, x.y, c.Qi, 0, 0, 0);
-#else
-            c.Pr[j] += t.x * x.x; c.Pi[j] += t.x * x.y; c.Qr[j] += t.y * x.x; c.Qi[j] += t.y * x.y;
-#endif
         }
     };
 
@@ -217,9 +217,6 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     v2f stage[2][8];
     const uint32_t ylane = (uint32_t)a.y2_hist + ((uint32_t)wt * a.nb * SPW + lo) * Y2B;
     auto store_staged = [&](int body, int h) {
-#ifdef LAB_NOSTORE
-        if (a.n_ch > 0) return;
-#endif
         if (body < 0 || !seg_live) return;
         const uint32_t at = ylane + (uint32_t)body * SPW * Y2B + 2 * h;
 #pragma unroll
@@ -248,12 +245,6 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         // 5th input, msd.hpp:228-247).  Inside a body, input u = P20 % 5 of super-step s = P20 / 5 is element 14 + u - 5 dd
         // of the window of output s + dd: output s + 3 starts at u = 1 (element 0), output s completes at u = 4 (element 18)
         constexpr int u = P20 % 5, s = P20 / 5;
-#ifdef LAB_NOPOST
-        if constexpr (u == 4) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) acc2[s & 3][i] += Y[i];
-        }
-#else
 #pragma unroll
         for (int dd = 0; dd < 4; dd++) {
             const int e = 14 + u - 5 * dd;
@@ -271,7 +262,6 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
 #pragma unroll
             for (int i = 0; i < 8; i++) asm volatile("" : "+v"(acc2[slot][i]));
         }
-#endif
         if constexpr (u == 4) {
 #pragma unroll
             for (int i = 0; i < 8; i++) stage[s & 1][i] = acc2[s & 3][i];
@@ -287,17 +277,11 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
             // this half-body's rows have landed (own DMAs: vmcnt; everybody's: barrier); the barrier also says
             // every wave is done with the other buffer, which the next half-body's rows may now overwrite
             const int hb = 2 * b + half;
-#ifdef LAB_NOSYNC
-            if (hb < 2) {
-#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             tph += G::HB;
             if (tph >= a.N) tph -= a.N;
             if (hb + 1 < 2 * n_bodies) issue_half(hb + 1, (half + 1) & 1, tph);
-#ifdef LAB_NOSYNC
-            }
-#endif
             // the outputs the previous half-body completed
             if (half == 0) store_staged(body - 1, 1);
             else store_staged(body, 0);
@@ -306,26 +290,24 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
             auto window = [&](auto ph_tag) {
                 constexpr int P20 = decltype(ph_tag)::value;   // phase inside the body
                 constexpr int ph = P20 % 10;                   // ... inside the half-body
+                // (the wave that feeds the matrix pipe goes first when both waves of the SIMD have something to issue:
+                // measured -1.5 % on the launch)
+                __builtin_amdgcn_s_setprio(1);
                 mfma_phase(ops, acc);
                 if constexpr (ph + 1 < 10) load_ops(P20 / 10, ph + 1, ops);
+                __builtin_amdgcn_s_setprio(0);
                 post(std::integral_constant<int, P20>{}, acc);
                 __builtin_amdgcn_sched_barrier(0);
             };
-            // Stage 2's first real output has the stage-1 outputs from phase 6 of the warm-up body on as its window:
-            // phases 0..5 of that body are nobody's input and are skipped.
-            auto run_half = [&](auto h_tag, const bool from6) {
+            auto run_half = [&](auto h_tag) {
                 constexpr int H = decltype(h_tag)::value;
-                if (!from6) {
-                    load_ops(H, 0, ops);
-                    window(std::integral_constant<int, H * 10 + 0>{});
-                    window(std::integral_constant<int, H * 10 + 1>{});
-                    window(std::integral_constant<int, H * 10 + 2>{});
-                    window(std::integral_constant<int, H * 10 + 3>{});
-                    window(std::integral_constant<int, H * 10 + 4>{});
-                    window(std::integral_constant<int, H * 10 + 5>{});
-                } else {
-                    load_ops(H, 6, ops);
-                }
+                load_ops(H, 0, ops);
+                window(std::integral_constant<int, H * 10 + 0>{});
+                window(std::integral_constant<int, H * 10 + 1>{});
+                window(std::integral_constant<int, H * 10 + 2>{});
+                window(std::integral_constant<int, H * 10 + 3>{});
+                window(std::integral_constant<int, H * 10 + 4>{});
+                window(std::integral_constant<int, H * 10 + 5>{});
                 window(std::integral_constant<int, H * 10 + 6>{});
                 window(std::integral_constant<int, H * 10 + 7>{});
                 window(std::integral_constant<int, H * 10 + 8>{});
@@ -333,12 +315,14 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
             };
             // (a wave whose segment group lies past the end of the data only keeps the workgroup's barriers and its share of the DMAs)
             if (seg_live) {
-                if (half == 0) run_half(std::integral_constant<int, 0>{}, b == 0);
-                else run_half(std::integral_constant<int, 1>{}, false);
+                if (half == 0) run_half(std::integral_constant<int, 0>{});
+                else run_half(std::integral_constant<int, 1>{});
             }
         }
     }
     store_staged(a.nb - 1, 1);                                  // the last half-body's outputs
+    // (the next item's first rows go to buffer 0, which every wave left before the barrier of the last half-body)
+    }
 }
 
 }   // namespace sdrxgpu

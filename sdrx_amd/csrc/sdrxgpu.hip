@@ -321,13 +321,22 @@ static hipError_t launch_k12m(const K12mLaunch &M, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
-static hipError_t k12m_set_attributes(int GS, int GT)
+// dynamic-LDS attribute + how many workgroups of the kernel one CU holds at once (the persistent grid's size)
+static hipError_t k12m_set_attributes(int GS, int GT, int *wgs_per_cu)
 {
     const int n = (int)k12m_lds_bytes(GS, GT);
-    if (GS == 2 && GT == 2) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    if (GS == 4 && GT == 2) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    if (GS == 2 && GT == 4) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    return hipErrorInvalidValue;
+    const void *f = (GS == 2 && GT == 2) ? reinterpret_cast<const void *>(&k_stage12m<2, 2>)
+                  : (GS == 4 && GT == 2) ? reinterpret_cast<const void *>(&k_stage12m<4, 2>)
+                  : (GS == 2 && GT == 4) ? reinterpret_cast<const void *>(&k_stage12m<2, 4>) : nullptr;
+    if (!f) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    if (e != hipSuccess) return e;
+    int k = 0;
+    if (GS == 2 && GT == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_stage12m<2, 2>, 64 * 4, (size_t)n);
+    else if (GS == 4 && GT == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_stage12m<4, 2>, 64 * 8, (size_t)n);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_stage12m<2, 4>, 64 * 8, (size_t)n);
+    *wgs_per_cu = k > 0 ? k : 1;
+    return e;
 }
 
 struct K12Entry {
@@ -457,6 +466,7 @@ struct sdrxgpu_bank {
     // ordered by host part, every part's share padded to whole workgroup sets of 16 * mGS slots
     bool mfma = false;
     int mGS = 2, mGT = 2;
+    int m_wgs_per_cu = 1, m_cus = 256;                // the persistent grid: workgroups the chip holds at once
     int2 *d_slots_m = nullptr, *d_slots_mp = nullptr;  // partners from the whole bank / from inside each host part
     int n_slots_m = 0, n_slots_mp = 0, n_pairs_m = 0;
     std::vector<int> part_gm;                         // set boundaries of the host parts
@@ -687,11 +697,12 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     b->WU = (halo + b->SB - 1) / b->SB;
     b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
     // Mixer + stage 1 on the f32 matrix pipe (k_stage12m): the 10 MS/s chain with translator tables, banks of
-    // 1 024 channels or more unless tuning says otherwise.  Its input rows start T1 - M1 samples in front of a body.
+    // 8 192 channels or more unless tuning says otherwise (measured against the vector kernels' automatic path, ms per block:
+    // 4 096 channels 0.50 / 0.45, 6 144: 0.66 / 0.64, 7 168: 0.76 / 0.72, 8 192: 0.79 / 0.83, 10 000: 0.94 / 1.02, 16 384:
+    // 1.54 / 1.61, 25 000: 2.33 / 2.48).  Its input rows start T1 - M1 samples in front of a body.
     const sdrxgpu_tuning tune0 = cfg->tuning ? *cfg->tuning : sdrxgpu_tuning{};
     {
-        const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && N > 0 && (N % 2) == 0 &&
-                         !b->pipelined;
+        const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && N > 0 && (N % 2) == 0;
         if (tune0.matrix_pipe > 2) {
             free_bank(b);
             return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe %u (0..2)", tune0.matrix_pipe);
@@ -699,7 +710,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         if (tune0.matrix_pipe == 2 && !can) {
             free_bank(b);
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = 2, but k_stage12m is built for the 10 MS/s chain "
-                        "(stages (5,17)(5,19)) with translator tables of even length, not pipelined");
+                        "(stages (5,17)(5,19)) with translator tables of even length");
         }
         // (automatic only where nothing else about the stage-1/2 kernel is asked for: a required fused tail, required pair lanes
         // or a forced geometry mean the vector kernels)
@@ -708,7 +719,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             free_bank(b);
             return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe = 2 goes with neither fused_tail = 2, pair_lanes = 2 nor k12_waves / k12_cpw");
         }
-        b->mfma = can && (tune0.matrix_pipe == 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 1024));
+        b->mfma = can && (tune0.matrix_pipe == 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 8192));
         if (b->mfma) {
             b->mGS = tune0.m_slot_groups ? (int)tune0.m_slot_groups : 2;
             b->mGT = tune0.m_seg_groups ? (int)tune0.m_seg_groups : 2;
@@ -748,6 +759,10 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         b->tile_b = (int)tune.tail_tile;
     }
     b->tail_generic = tune.tail_generic != 0;
+    if (tune.fused_tail > 2 || tune.pair_lanes > 2) {
+        free_bank(b);
+        return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.fused_tail %u / tuning.pair_lanes %u (0 = auto, 1 = never, 2 = require)", tune.fused_tail, tune.pair_lanes);
+    }
     if (tune.host_parts > 8) {
         free_bank(b);
         return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.host_parts %u (0..8)", tune.host_parts);
@@ -1081,7 +1096,8 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         b->d_slots_mp = b->d_slots_m + slots_all.size();
         hipError_t e = hipMemcpy(b->d_slots_m, slots_all.data(), slots_all.size() * sizeof(int2), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(b->d_slots_mp, slots_parts.data(), slots_parts.size() * sizeof(int2), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = k12m_set_attributes(b->mGS, b->mGT);
+        if (e == hipSuccess) e = k12m_set_attributes(b->mGS, b->mGT, &b->m_wgs_per_cu);
+        b->m_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "k_stage12m set-up failed: %s", hipGetErrorString(e));
@@ -1114,7 +1130,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         (rc = dev_alloc(b, (void **)&b->d_xr[1], b->x_capacity * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_tables, 2 * (size_t)b->n_ch * b->tbl_stride * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_y2, ((size_t)b->n_ch + (b->mfma ? 1 : 0)) * b->y2_stride * sizeof(float2))) ||   // (k_stage12m: a spare row for places without channel)
-        (b->pipelined && (rc = dev_alloc(b, (void **)&b->d_y2b, (size_t)b->n_ch * b->y2_stride * sizeof(float2)))) ||
+        (b->pipelined && (rc = dev_alloc(b, (void **)&b->d_y2b, ((size_t)b->n_ch + (b->mfma ? 1 : 0)) * b->y2_stride * sizeof(float2)))) ||
         (!b->fused && (rc = dev_alloc(b, (void **)&b->d_hist[0], (size_t)b->n_ch * b->y2_hist * sizeof(float2)))) ||
         (!b->fused && (rc = dev_alloc(b, (void **)&b->d_hist[1], (size_t)b->n_ch * b->y2_hist * sizeof(float2)))) ||
         (b->fused && (rc = dev_alloc(b, (void **)&b->d_y3, (size_t)b->n_ch * b->y3_stride * sizeof(float2)))) ||
@@ -1519,6 +1535,8 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
         M.L.args.cg0 = g_lo;
         M.L.args.n_chgroups = g_hi;
         M.L.args.n_cgx = (g_hi - g_lo + 7) / 8 * 8;
+        // (the kernel walks items blockIdx.x, + gridDim.x, ...: a grid capped at the workgroups the chip holds at once makes it
+        // persistent -- measured 3 % slower than one workgroup per item, which lets the dispatcher even out the last round)
         M.L.grid = M.L.args.n_cgx * M.L.args.n_wt;
         M.pa.slots = whole ? b->d_slots_m : b->d_slots_mp;
         M.pa.group_conj = nullptr;

@@ -6,7 +6,7 @@ in the bank (a channel's partner, repeated instances), host entry or device entr
 import numpy as np
 import pytest
 
-from conftest import RTOL, rel_err_rows, margin
+from conftest import RTOL, load_golden, regen_blocks, rel_err, rel_err_rows, margin
 from sdrx_amd import bank as sb, chains, synth
 
 pytestmark = pytest.mark.gpu
@@ -127,7 +127,7 @@ def test_a_channels_bits_do_not_depend_on_who_else_is_in_the_bank():
 
 def test_large_bank_by_default_host_parts_and_oracle(oracle):
     ch = chains.chain("10")
-    n_ch = 5000                                            # two host parts, several time tiles, 1 200 distinct offsets
+    n_ch = 10000                                           # the bench workload: the default path from 8 192 channels; four host parts
     offs = chains.offsets_cycled(n_ch, ch.N)
     tabs = sb.translators_for(ch, offs)
     L = ch.block_len
@@ -143,11 +143,11 @@ def test_large_bank_by_default_host_parts_and_oracle(oracle):
     for c in range(0, n_ch - ch.N, 97):
         assert np.array_equal(iq[c].view(np.uint32), iq[c + ch.N].view(np.uint32))
     worst_iq = worst_au = 0.0
-    for c in (0, 1, 599, 600, 601, 1199, 1200, 2559, 2560, 4999):
+    for c in (0, 1, 599, 600, 601, 1199, 1200, 2559, 2560, 4999, 7777, 9999):
         riq, rau = _oracle(oracle, ch, [tabs[c]], blocks)
         worst_iq = max(worst_iq, rel_err_rows(iq[c:c + 1], riq))
         worst_au = max(worst_au, rel_err_rows(au[c:c + 1], rau))
-    margin("matrix_pipe_5000ch_vs_oracle", iq=worst_iq, audio=worst_au)
+    margin("matrix_pipe_10000ch_vs_oracle", iq=worst_iq, audio=worst_au)
     assert worst_iq <= RTOL and worst_au <= RTOL
 
 
@@ -179,3 +179,53 @@ def test_matrix_pipe_is_refused_where_it_cannot_run():
         sb.ChannelBank(sb.translators_for(ch, [1, -1]), ch.stage_tuples(), tuning={"matrix_pipe": REQ, "m_slot_groups": 3, "m_seg_groups": 1})
     with pytest.raises(sb.SdrxGpuError):
         sb.ChannelBank([None, None], ch.stage_tuples(), tuning={"matrix_pipe": REQ})        # nobody mixes: no table length to space the segments by
+
+
+@pytest.mark.parametrize("name", ["g2_fs10000", "g3_fs10000_noise", "g4_fs10000_impulse", "g4_fs10000_dc", "g4_fs10000_tone",
+                                  "g5_fs10000_ftfir", "g6_fs10000_ragged"])
+def test_golden_vectors_through_the_matrix_pipe(name):
+    """The reference's own outputs (compiled from its headers, tests/golden): offsets {0, +-1, 37, -415, 479, 480}, noise
+    only, impulse / DC / tone known answers, --ftfir, ragged call lengths."""
+    g = load_golden(name)
+    ch, blocks = regen_blocks(g)
+    tabs = [g["tables"][i] if int(o) != 0 else None for i, o in enumerate(g["offsets"])]
+    if all(t is None for t in tabs):
+        pytest.skip("nobody mixes: no translator length to space the segments by (such banks run the vector kernels)")
+    iq, au, info = _run(ch, tabs, blocks, ftfir="ftfir" in name)
+    assert info.matrix_pipe == 1
+    e_iq, e_au = rel_err_rows(iq, g["iq"]), rel_err_rows(au, g["audio_lf"])
+    margin(f"golden_matrix_pipe[{name}]", iq=e_iq, audio=e_au)
+    assert e_iq <= RTOL and e_au <= RTOL
+
+
+def test_200_blocks_in_ragged_calls_through_the_matrix_pipe(oracle):
+    """tests/test_gpu_long_stream.py's stream (6.4 s of signal, three carriers up to 0.6 of full scale, ragged calls) through
+    k_stage12m: within 1e-5 of the free-running oracle at every block, exact sample counts."""
+    from test_gpu_long_stream import N_BLOCKS, OFFS, _stream_and_cuts
+    ch = chains.chain("10")
+    tabs = sb.translators_for(ch, OFFS)
+    n_ch, L = len(OFFS), ch.block_len
+    stream, cuts, total = _stream_and_cuts(ch, tabs)
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": REQ})
+    ob = oracle.bank(tabs, ch.stage_tuples())
+    got_iq = np.zeros((n_ch, N_BLOCKS * 512), np.complex64)
+    got_au = np.zeros((n_ch, N_BLOCKS * 512), np.float32)
+    p_out = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        iq, au = bank.process(stream(a, b))
+        assert iq.shape[1] == b // 625 - a // 625
+        got_iq[:, p_out:p_out + iq.shape[1]] = iq
+        got_au[:, p_out:p_out + iq.shape[1]] = au
+        p_out += iq.shape[1]
+    info = bank.info()
+    assert info.samples_in == total and info.samples_out == N_BLOCKS * 512 == p_out and info.matrix_pipe == 1
+    bank.close()
+    worst_iq = worst_au = last_iq = last_au = 0.0
+    for k in range(N_BLOCKS):
+        r_iq, r_au = ob.process(stream(k * L, (k + 1) * L), threads=n_ch)
+        sl = slice(k * 512, (k + 1) * 512)
+        last_iq = max(rel_err(got_iq[c, sl], r_iq[c]) for c in range(n_ch))
+        last_au = max(rel_err(got_au[c, sl], r_au[c]) for c in range(n_ch))
+        worst_iq, worst_au = max(worst_iq, last_iq), max(worst_au, last_au)
+    margin("long_stream_200_blocks[matrix_pipe]", worst_iq=worst_iq, worst_audio=worst_au, last_block_iq=last_iq, last_block_audio=last_au)
+    assert worst_iq <= RTOL and worst_au <= RTOL
