@@ -76,8 +76,9 @@ def _free_port():
 def spawn_ranks(args):
     """`--gpus N` without a launcher around us: be the launcher.  This process never initialises a GPU (nothing
     below imports torch.cuda state or loads libsdrxgpu); the ranks are fresh child processes."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    # (--standalone: torchrun's own rendezvous picks and binds a free port itself -- no window between finding a port and using it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
@@ -113,7 +114,7 @@ def flops_per_channel_sample(chain, n_stages):
     return total
 
 
-def profile_facts(n_ch, fused, pair):
+def profile_facts(n_ch, fused, pair, matrix=False):
     """HBM bytes per k_stage12 launch and the clock the chip sustains, from the rocprofv3 --pmc passes of this build
     (tools_pmc.sh -> profiles/*_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     None when no profile of this channel count / kernel path is committed."""
@@ -121,7 +122,8 @@ def profile_facts(n_ch, fused, pair):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
-            if d.get("channels") == n_ch and bool(d.get("fused_tail", False)) == bool(fused) and bool(d.get("pair_lanes", False)) == bool(pair):
+            if (d.get("channels") == n_ch and bool(d.get("fused_tail", False)) == bool(fused) and bool(d.get("pair_lanes", False)) == bool(pair)
+                    and bool(d.get("matrix_pipe", False)) == bool(matrix)):
                 return d, os.path.basename(f)
         except (OSError, ValueError):
             pass
@@ -461,16 +463,19 @@ def main():
         f12 = flops_per_channel_sample(ch, 3 if fused else 2)     # what k_stage12 computes per channel-sample
         f_all = flops_per_channel_sample(ch, len(ch.stages))
         ach_tf = f12 * units / (k12_ms / 1e3) / 1e12 if k12_n else None
-        prof, prof_src = profile_facts(n_ch, fused, pair_seen[n_ch])
+        matrix = bool(matrix_seen[n_ch])
+        prof, prof_src = profile_facts(n_ch, fused, pair_seen[n_ch], matrix)
         n_y2, n_y3 = L // (ch.stages[0].m * ch.stages[1].m), L // (ch.stages[0].m * ch.stages[1].m * ch.stages[2].m)
         if fused:     # k_tail4: [hist3 | y3] + the range-boundary buffer in, decimated IQ out (k_agc reads the caller's rows)
             tail_bytes = n_ch * (8.0 * (n_y3 + 80) + 8.0 * 40 * ((n_y2 + 767) // 768) + 8.0 * 512)
         else:         # k_tail_s: the stage-2 scratch in, decimated IQ out
             tail_bytes = n_ch * (8.0 * n_y2 + 8.0 * 512)
         kern = {
-            "k_stage12": {"ms": k12_ms, "bound": "valu_fp32", "flops_per_unit": f12, "achieved_tflops": ach_tf,
+            "k_stage12": {"ms": k12_ms, "bound": "mfma" if matrix else "valu_fp32", "flops_per_unit": f12, "achieved_tflops": ach_tf,
                           "frac": ach_tf / FP32_PEAK_TF if ach_tf else None,
-                          "does": "mixer + stages 1-2" + (" + stage 3 of the workgroup's own range (fused)" if fused else "")},
+                          "does": ("k_stage12m: mixer + stage 1 as f32 MFMAs (16x16x4, conjugate pairs share four real products), "
+                                   "stage 2 on the vector ALU" if matrix else
+                                   "mixer + stages 1-2" + (" + stage 3 of the workgroup's own range (fused)" if fused else ""))},
             "k_tail": {"ms": k["k_tail"][0], "bound": "hbm", "algorithmic_bytes": tail_bytes,
                        "achieved_gbs": tail_bytes / (k["k_tail"][0] / 1e3) / 1e9 if k["k_tail"][1] else None,
                        "frac": tail_bytes / (k["k_tail"][0] / 1e3) / 1e9 / HBM_PEAK_GBS if k["k_tail"][1] else None,
@@ -499,6 +504,7 @@ def main():
                                (f"; two channels per lane in k_stage12, {pair_seen[n_ch] - 1} conjugate pairs share the mixer" if pair_seen[n_ch] else "") +
                                ("; mixer + stage 1 on the f32 matrix pipe (k_stage12m)" if matrix_seen[n_ch] else ""),
                 "realtime_factor": value * 1e6 / (n_ch * world * ch.fs),
+                "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),   # (set before the HIP runtime started: two banks' streams need queues of their own)
                 "settle_steps": SETTLE_STEPS,    # untimed, before the W warm-up steps (clock settling, see time_bank)
                 "call_semantics": "drop-in: call k returns block k" if not args.pipelined else
                                   "pipelined: call k returns block k-1 (bit-identical outputs, one block of latency)",
@@ -507,7 +513,9 @@ def main():
                 # the ceiling that binds: fp32 vector issue.  achieved = the flop the reference's
                 # algorithm does per channel-sample in this kernel x channel-samples per launch / the kernel's mean
                 # duration (HIP events on the bank's stream, inside the timed region)
-                "bound": "valu_fp32", "kernel": "k_stage12",
+                # matrix path: the f32 MFMA and the vector ALU share the FP32 datapath (measured additive): one
+                # ceiling of 157.3 TFLOP/s for both, the dense f32 MFMA peak of MI355X_MICROARCH.md
+                "bound": "mfma" if matrix else "valu_fp32", "kernel": "k_stage12m" if matrix else "k_stage12",
                 "achieved": ach_tf, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": ach_tf / FP32_PEAK_TF if ach_tf else None,
                 "flops_per_unit": f12, "flops_per_unit_whole_step": f_all,

@@ -67,9 +67,16 @@ class PipelinedFanout:
         fan.done(k)                 # buffer k % 2 may be refilled once what was enqueued so far has run
 
     With one rank nothing is communicated unless ``force`` (rehearsal of the RCCL path on one GPU).  ``gloo`` / CPU
-    tensors take the same calls (no streams; ``async_op`` broadcasts)."""
+    tensors take the same calls (no streams; ``async_op`` broadcasts).
 
-    def __init__(self, dist, bufs, src=0, force=False, inline=False):
+    ``consumer_stream``: the stream on which the buffers are READ (the bank's stream: ``ChannelBank(stream=...)``).
+    ``done(k)`` records "buffer k % 2 is free" there and the refill waits for that record, so it must be the stream
+    the bank's kernels run on -- a bank on a stream of its own while ``done`` recorded on another would let the
+    broadcast of block k+2 overwrite a ring block k's kernels still read.  Default: the stream that is current when
+    the fan-out is built (bench.py builds it with the bank's stream current); ``get`` and ``done`` refuse to run
+    with any other stream current."""
+
+    def __init__(self, dist, bufs, src=0, force=False, inline=False, consumer_stream=None):
         self.dist = dist
         self.inline = inline        # A/B only: the broadcast of block k in line on the compute stream, at get(k)
         self.bufs = list(bufs)
@@ -84,9 +91,10 @@ class PipelinedFanout:
             import torch
             self._torch = torch
             self.comm = torch.cuda.Stream()
+            self.consumer = consumer_stream if consumer_stream is not None else torch.cuda.current_stream()
             self.free = [torch.cuda.Event(), torch.cuda.Event()]
             for e in self.free:
-                e.record()
+                e.record(self.consumer)
 
     def post(self, k, block=None):
         """Start moving block k into buffer k % 2; ``block`` is needed on rank ``src`` only."""
@@ -117,15 +125,22 @@ class PipelinedFanout:
                 self.bufs[i].copy_(self._local[i])
             self.dist.broadcast(self.bufs[i], src=self.src)
             return self.bufs[i]
+        self._check_stream()
         w, self._work[i] = self._work[i], None
         if w is not None:
             w.wait()
         return self.bufs[i]
 
+    def _check_stream(self):
+        if self.active and self.cuda and self._torch.cuda.current_stream() != self.consumer:
+            raise RuntimeError("PipelinedFanout: get()/done() must run with the consumer stream current "
+                               "(the stream the bank reads the buffers on)")
+
     def done(self, k):
         """Everything that reads buffer k % 2 has been enqueued on the current stream."""
         if self.active and self.cuda:
-            self.free[k & 1].record()
+            self._check_stream()
+            self.free[k & 1].record(self.consumer)
 
 
 def max_over_ranks(dist, seconds: float, device="cpu") -> float:

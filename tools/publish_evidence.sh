@@ -1,26 +1,23 @@
 #!/bin/bash
-# copy what tools/collect_evidence.sh left under gpurun_out/ev/ into profiles/ under a tag: tools/publish_evidence.sh r02_c
+# copy what tools/collect_evidence.sh left under gpurun_out/ev/ into profiles/ under a tag: tools/publish_evidence.sh r03_a
 set -e
 cd "$(dirname "$0")/.."
 T=$1; E=gpurun_out/ev; P=profiles
 j() { grep '^{' "$1" | tail -1 > "$2"; }
 j $E/bench.log $P/${T}_bench.json
-j $E/bench_separate_tail.log $P/${T}_bench_separate_tail.json
-j $E/bench_single_lane.log $P/${T}_bench_single_lane.json
-j $E/bench_single_lane_separate_tail.log $P/${T}_bench_single_lane_separate_tail.json
+j $E/bench_vector.log $P/${T}_bench_vector_kernels.json
+j $E/bench_vector_separate_tail.log $P/${T}_bench_vector_kernels_separate_tail.json
 j $E/bench_rccl_1rank.log $P/${T}_bench_rccl_1rank.json
-j $E/bench_rccl_1rank_inline.log $P/${T}_bench_rccl_1rank_inline.json
-j $E/bench_under_rocprof.log $P/${T}_bench_under_rocprof.json
-j $E/bench_under_rocprof_separate_tail.log $P/${T}_bench_under_rocprof_single_lane_separate_tail.json
+j $E/bench_under_rocprof_trace.log $P/${T}_bench_under_rocprof.json
+j $E/bench_under_rocprof_trace_vector.log $P/${T}_bench_under_rocprof_vector_kernels.json
 cp "$(ls -t $E/trace/runc/*_kernel_stats.csv | head -1)" $P/${T}_kernel_stats.csv
-cp "$(ls -t $E/trace_sep/runc/*_kernel_stats.csv | head -1)" $P/${T}_kernel_stats_single_lane_separate_tail.csv
-cp $E/pmc_fused/summary.txt $P/${T}_pmc_summary.txt;                 cp $E/pmc_fused/traffic.json $P/${T}_traffic.json
-cp $E/pmc_separate/summary.txt $P/${T}_single_lane_separate_tail_pmc_summary.txt; cp $E/pmc_separate/traffic.json $P/${T}_single_lane_separate_tail_traffic.json
-cp $E/pmc_pair_separate/summary.txt $P/${T}_pair_separate_tail_pmc_summary.txt;   cp $E/pmc_pair_separate/traffic.json $P/${T}_pair_separate_tail_traffic.json
-cp $E/ubench_valu.txt $P/r02_ubench_valu.txt; cp $E/ubench_hbm_read.txt $P/r02_ubench_hbm_read.txt
-python3 - <<'PY'
-import json
-old = json.load(open('profiles/r02_parity_margins.json'))
+cp "$(ls -t $E/trace_vector/runc/*_kernel_stats.csv | head -1)" $P/${T}_kernel_stats_vector_kernels.csv
+cp $E/pmc_matrix/summary.txt $P/${T}_pmc_summary.txt;                 cp $E/pmc_matrix/traffic.json $P/${T}_traffic.json
+cp $E/pmc_vector/summary.txt $P/${T}_vector_kernels_pmc_summary.txt;  cp $E/pmc_vector/traffic.json $P/${T}_vector_kernels_traffic.json
+cp $E/ubench_valu.txt $P/${T}_ubench_valu.txt; cp $E/ubench_hbm_read.txt $P/${T}_ubench_hbm_read.txt; cp $E/ubench_mfma_fir.txt $P/${T}_ubench_mfma_fir.txt
+tail -3 $E/gpu_tests.log > $P/${T}_gpu_tests_tail.txt
+python3 - "$T" <<'PY'
+import json, sys
 tests = {}
 for l in open('gpurun_out/ev/parity_margins.jsonl'):
     r = json.loads(l); name = r.pop('test')
@@ -30,6 +27,8 @@ for l in open('gpurun_out/ev/parity_margins.jsonl'):
             else: tests[name].setdefault(k, v)
     else:
         tests[name] = r
-json.dump({"note": old["note"], "tests": tests}, open('profiles/r02_parity_margins.json', 'w'), indent=1)
+note = ("worst relative error each GPU parity test saw against the oracle / the golden vectors (comparator of tests/conftest.py: "
+        "|got - ref| / max(|ref|, rms of the channel)); tolerance 1e-5")
+json.dump({"note": note, "tests": tests}, open('profiles/%s_parity_margins.json' % sys.argv[1], 'w'), indent=1)
 PY
 echo published $T

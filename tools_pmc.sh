@@ -5,6 +5,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8      # (what bench.py sets for itself; under rocprofv3 the runtime starts before the program does)
 i=0
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
@@ -13,7 +14,10 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra-configs "$@" > $OUT/pass$i.log 2>&1
-  echo "pass $i ($SET): exit $?"
+  rc=$?
+  echo "pass $i ($SET): exit $rc"
+  # a pass killed at its time limit means a hang: no further GPU process after it
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pass $i was killed at its time limit: stopping"; exit 99; fi
 done
 python3 - "$@" <<PY
 import csv, glob, collections, json, re, sys
@@ -62,6 +66,7 @@ if "k_stage12" in out:
 if b3:
     out["fused_tail"] = "fused" in b3["config"]["kernel_path"].split("(")[0]
     out["pair_lanes"] = "two channels per lane" in b3["config"]["kernel_path"]
+    out["matrix_pipe"] = "k_stage12m" in b3["config"]["kernel_path"]
 json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
