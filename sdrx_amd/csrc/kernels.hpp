@@ -1031,6 +1031,8 @@ struct TailArgs {
     // body-major storage of the new stage-2 outputs (see k_stage12): geometry of the launch that wrote them
     int y2b, seg_len, ph_len, spw_shift, spw, nb, P;       // seg_len = bps*Y2B, ph_len = nb*Y2B
     int y2b_shift;          // log2(y2b)
+    int half_split;         // 1: written by k_stage12m -- a body's four outputs of a segment lie as two pairs, one in each of the
+                            // body's two half-body rows: [time-wave][2 body + h][segment][2] (kernels_mfma.hpp); y2b is 4
     float rcp_seg_len, rcp_ph_len, rcp_y2b;
     float hA[kMaxHalfTaps];
     float hB[kMaxHalfTaps];
@@ -1049,6 +1051,7 @@ __device__ __forceinline__ int y2_storage_index(const TailArgs &a, int j)
     const int g = seg >> a.spw_shift;
     const int sl = seg & (a.spw - 1);
     const int wt = g * a.P + pp;
+    if (a.half_split) return ((wt * 2 * a.nb + 2 * body + (q >> 1)) * a.spw + sl) * 2 + (q & 1);
     return ((wt * a.nb + body) * a.spw + sl) * a.y2b + q;
 }
 
@@ -1188,6 +1191,8 @@ __device__ __forceinline__ int y2_group_index(const TailArgs &a, int j)
         const int r = j - __mul24(seg, a.seg_len);
         const int body = r >> a.y2b_shift;
         const int g = seg >> a.spw_shift, sl = seg & (a.spw - 1);
+        // (half_split, y2b == 4: the group's first pair; its second pair lies one half-body row = 2 * spw entries further)
+        if (a.half_split) return ((__mul24(g, a.nb) + body) << (a.spw_shift + 2)) | (sl << 1);
         return ((__mul24(g, a.nb) + body) << (a.spw_shift + a.y2b_shift)) | (sl << a.y2b_shift);
     }
     return y2_storage_index(a, j);
@@ -1248,16 +1253,19 @@ __global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
     // past the end of the row re-reads the last group -- whole groups are always allocated and written
     // (k_stage12 stores Y2B outputs at a time), and entries >= n_row are never inside a FIR window.
     const int p_last = (n_row - 1) & ~(G - 1);
-    auto group_src = [&](int i) -> const float2 * {
+    // off2: where the group's second pair lies -- the next two entries, or (half_split, among the new outputs) one half-body row further
+    auto group_src = [&](int i, int &off2) -> const float2 * {
         const int p = min(p0g + (i << gsh), p_last);
+        off2 = (a.half_split && p >= a.hist) ? 2 * a.spw : 2;
         return p < a.hist ? hin + p : ynew + y2_group_index(a, p - a.hist);
     };
     for (int i0 = 0; i0 < ngrp; i0 += 512) {
         const int ia = i0 + tid, ib = i0 + tid + 256;
-        const float2 *sa = group_src(ia), *sb = group_src(ib);
+        int sa2, sb2;
+        const float2 *sa = group_src(ia, sa2), *sb = group_src(ib, sb2);
         if (G == 4) {
-            const v4f a0 = *reinterpret_cast<const v4f *>(sa), a1 = *reinterpret_cast<const v4f *>(sa + 2);
-            const v4f b0 = *reinterpret_cast<const v4f *>(sb), b1 = *reinterpret_cast<const v4f *>(sb + 2);
+            const v4f a0 = *reinterpret_cast<const v4f *>(sa), a1 = *reinterpret_cast<const v4f *>(sa + sa2);
+            const v4f b0 = *reinterpret_cast<const v4f *>(sb), b1 = *reinterpret_cast<const v4f *>(sb + sb2);
             if (ia < ngrp) { s2v[2 * ia] = a0; s2v[2 * ia + 1] = a1; }
             if (ib < ngrp) { s2v[2 * ib] = b0; s2v[2 * ib + 1] = b1; }
         } else {

@@ -211,14 +211,18 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     };
 
     // The two stage-2 outputs a half-body completes wait in `stage` and leave right after the NEXT barrier, as one
-    // 16-byte store per channel (outputs 2 h, 2 h + 1 of the body are neighbours in the body-major scratch): by the
+    // 16-byte store per channel: by the
     // time the following s_waitcnt vmcnt(0) comes they are a whole half-body old.  (Stored where they complete, they
     // made every barrier wait for a store round trip: 0.85 against 0.64 ms for the launch.)
+    // Scratch layout: k_stage12's body-major rows with HALF-bodies as the bodies -- [time-wave][half-body][segment][2] --, so that
+    // the 16 lanes of a channel write 256 contiguous bytes per store and no 32-byte sector is written in two goes (with whole
+    // bodies of four outputs per segment the two halves of every sector came ten phases apart: 2.0 GB of HBM writes per
+    // launch for 1.07 GB of outputs).  The tail kernels are told so (y2b = 2, twice the bodies).
     v2f stage[2][8];
-    const uint32_t ylane = (uint32_t)a.y2_hist + ((uint32_t)wt * a.nb * SPW + lo) * Y2B;
+    const uint32_t ylane = (uint32_t)a.y2_hist + ((uint32_t)wt * (2 * a.nb) * SPW + lo) * 2;
     auto store_staged = [&](int body, int h) {
         if (body < 0 || !seg_live) return;
-        const uint32_t at = ylane + (uint32_t)body * SPW * Y2B + 2 * h;
+        const uint32_t at = ylane + (uint32_t)(2 * body + h) * SPW * 2;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             *reinterpret_cast<v4f *>(y2_out + (size_t)(yrow[2 * r] + at)) =

@@ -1714,6 +1714,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         t.rcp_seg_len = 1.0f / (float)t.seg_len;
         t.rcp_ph_len = 1.0f / (float)t.ph_len;
         t.rcp_y2b = 1.0f / (float)t.y2b;
+        t.half_split = b->mfma ? 1 : 0;     // k_stage12m stores by half-bodies of two outputs (kernels_mfma.hpp)
         t.n_tiles = std::max(1, (t.n_b + b->tile_b - 1) / b->tile_b);
         if (t.n_b > b->keep_stride) return fail(SDRXGPU_ERR_HIP, "internal: %d outputs > keep_stride %d", t.n_b, b->keep_stride);
         job->valid = true;

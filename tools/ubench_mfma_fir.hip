@@ -216,8 +216,5 @@ int main()
     run<1, 2>("+ coefficients, tap 16, combos", 2, src, h2);
     run<2, 2>("+ stage 2 (whole phase)", 2, src, h2);
     run<3, 2>("VALU part only", 2, src, h2);
-    run<0, 3>("mfma + operand reads", 3, src, h2);
-    run<1, 3>("+ coefficients, tap 16, combos", 3, src, h2);
-    run<2, 3>("+ stage 2 (whole phase)", 3, src, h2);
     return 0;
 }
