@@ -321,22 +321,13 @@ static hipError_t launch_k12m(const K12mLaunch &M, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
-// dynamic-LDS attribute + how many workgroups of the kernel one CU holds at once (the persistent grid's size)
-static hipError_t k12m_set_attributes(int GS, int GT, int *wgs_per_cu)
+static hipError_t k12m_set_attributes(int GS, int GT)
 {
     const int n = (int)k12m_lds_bytes(GS, GT);
-    const void *f = (GS == 2 && GT == 2) ? reinterpret_cast<const void *>(&k_stage12m<2, 2>)
-                  : (GS == 4 && GT == 2) ? reinterpret_cast<const void *>(&k_stage12m<4, 2>)
-                  : (GS == 2 && GT == 4) ? reinterpret_cast<const void *>(&k_stage12m<2, 4>) : nullptr;
-    if (!f) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    if (e != hipSuccess) return e;
-    int k = 0;
-    if (GS == 2 && GT == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_stage12m<2, 2>, 64 * 4, (size_t)n);
-    else if (GS == 4 && GT == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_stage12m<4, 2>, 64 * 8, (size_t)n);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_stage12m<2, 4>, 64 * 8, (size_t)n);
-    *wgs_per_cu = k > 0 ? k : 1;
-    return e;
+    if (GS == 2 && GT == 2) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    if (GS == 4 && GT == 2) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    if (GS == 2 && GT == 4) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    return hipErrorInvalidValue;
 }
 
 struct K12Entry {
@@ -466,7 +457,6 @@ struct sdrxgpu_bank {
     // ordered by host part, every part's share padded to whole workgroup sets of 16 * mGS slots
     bool mfma = false;
     int mGS = 2, mGT = 2;
-    int m_wgs_per_cu = 1, m_cus = 256;                // the persistent grid: workgroups the chip holds at once
     int2 *d_slots_m = nullptr, *d_slots_mp = nullptr;  // partners from the whole bank / from inside each host part
     int n_slots_m = 0, n_slots_mp = 0, n_pairs_m = 0;
     std::vector<int> part_gm;                         // set boundaries of the host parts
@@ -1096,8 +1086,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         b->d_slots_mp = b->d_slots_m + slots_all.size();
         hipError_t e = hipMemcpy(b->d_slots_m, slots_all.data(), slots_all.size() * sizeof(int2), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(b->d_slots_mp, slots_parts.data(), slots_parts.size() * sizeof(int2), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = k12m_set_attributes(b->mGS, b->mGT, &b->m_wgs_per_cu);
-        b->m_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (e == hipSuccess) e = k12m_set_attributes(b->mGS, b->mGT);
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "k_stage12m set-up failed: %s", hipGetErrorString(e));

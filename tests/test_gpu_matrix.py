@@ -73,7 +73,7 @@ def test_matrix_pipe_is_close_to_the_vector_kernels_but_not_equal():
     m = _run(ch, tabs, blocks)
     v = _run(ch, tabs, blocks, tuning={"matrix_pipe": OFF})
     assert v[2].matrix_pipe == 0
-    assert rel_err_rows(m[0], v[0]) <= 5e-6
+    assert rel_err_rows(m[0], v[0]) <= RTOL              # (two summation orders, each within its own error of the exact result)
     assert not np.array_equal(m[0].view(np.uint32), v[0].view(np.uint32))      # (if this ever fails the two paths have become one)
 
 
@@ -167,7 +167,7 @@ def test_matrix_pipe_with_ftfir_squelch_fm_lf_agc_and_audio_fir(oracle):
     v = _run(ch, tabs, blocks, tuning={"matrix_pipe": OFF}, **kw)
     e_iq, e_au = rel_err_rows(m[0], v[0]), rel_err_rows(m[1], v[1])
     margin("matrix_pipe_ftfir_squelch_fm_vs_vector_kernels", iq=e_iq, audio=e_au)
-    assert e_iq <= 5e-6 and e_au <= RTOL
+    assert e_iq <= RTOL and e_au <= RTOL
 
 
 def test_matrix_pipe_is_refused_where_it_cannot_run():
