@@ -20,8 +20,9 @@
 // bank.  Taps 0..15 go through four K = 4 steps; tap 16 starts the accumulators (vector multiply), which costs less
 // issue time than a fifth, mostly empty K step (the f32 MFMA and the vector ALU do not overlap: measured additive).
 //
-// Geometry.  A wave = one tile of 16 slots (pairs) x 16 time segments (MFMA M x N); lanes hold C/D as
-// [slot 4*(lane>>4)+r][segment lane&15], r = 0..3.  A workgroup = GS slot groups x GT segment groups = GS*GT waves that
+// Geometry.  A wave = one tile of 16 slots (pairs) x 16 time segments, as two MFMA tiles of 8 slots x 16 segments: the
+// 16 rows of an MFMA are 8 slots x {Cr, Ci}, so that a lane's accumulator registers hold (P, Q) of a slot side by side
+// (C/D row 4*(lane>>4)+r = slot 2*(lane>>4) + (r>>1), part r&1; column = segment lane&15).  A workgroup = GS slot groups x GT segment groups = GS*GT waves that
 // share GT*16 input rows and GS*16 translator rows in LDS (LDS-DMA, two buffers of half a body = 50 samples + 12 of
 // history each).  Segments, bodies (100 samples = 20 stage-1 outputs = 4 stage-2 outputs), warm-up and the body-major
 // stage-2 scratch are k_stage12's, so the tail kernels do not know which kernel ran.
@@ -48,6 +49,11 @@ struct TileGeomM {
     static constexpr int pairs_per_wave = (pairs + waves - 1) / waves;
 };
 
+// 1: the first six phases of a lane's warm-up body are skipped (nobody's input; -1.5 % on the launch although the second
+// path through the half-body costs registers: 256 VGPRs and a few spills instead of 209)
+#ifndef SDRX_M_TRIM
+#define SDRX_M_TRIM 1
+#endif
 struct Stage12mTaps {
     float h1[17];
     float h2[10];       // h2[0 .. 9]; h2[18 - e] = h2[e] (the reference reads that half only, msd.hpp:309-331): 10 scalar register pairs, not 19
@@ -61,6 +67,7 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     using G = TileGeomM<GS, GT>;
     constexpr int SB = 100, Y2B = 4, SPW = 16;
     constexpr int RB = G::row_bytes;
+    constexpr bool TRIM = SDRX_M_TRIM != 0;
     extern __shared__ __attribute__((aligned(16))) char lds_m[];
 
     const int tid = threadIdx.x;
@@ -87,14 +94,14 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     // ---- what this lane stores: slots 4*hi + r of the wave's group, both channels of each.  A place without channel
     // (empty slot, no partner) stores into the spare row behind the last channel's: no branch around any store ----
     const int slot_base = (cgm * GS + sg) * 16;
-    uint32_t yrow[8];                                       // [2 r + (0: channel A, 1: channel B)]: first element of the channel's scratch row
+    uint32_t yrow[8];                                       // [4 g + 2 e + (0: channel A, 1: channel B)]: first element of the channel's scratch row
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int s = slot_base + 4 * hi + r;
+    for (int i = 0; i < 4; i++) {                           // i = 2 g + e: slot 8 g + 2 hi + e of the wave's group
+        const int s = slot_base + 8 * (i >> 1) + 2 * hi + (i & 1);
         const int2 sl = s < pa.n_slots ? pa.slots[s] : make_int2(-1, -1);
         const int ca = sl.x >= 0 ? sl.x : a.n_ch, cb = (sl.x >= 0 && sl.y >= 0) ? sl.y : a.n_ch;
-        yrow[2 * r] = (uint32_t)ca * (uint32_t)a.y2_stride;
-        yrow[2 * r + 1] = (uint32_t)cb * (uint32_t)a.y2_stride;
+        yrow[2 * i] = (uint32_t)ca * (uint32_t)a.y2_stride;
+        yrow[2 * i + 1] = (uint32_t)cb * (uint32_t)a.y2_stride;
     }
     const int g_mine = g_first + tg;                        // this wave's segment group
     const int wt = g_mine * a.P + p;                        // its time-wave in k_stage12's numbering (scratch layout)
@@ -141,9 +148,13 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     };
 
     // ---- operand addresses (byte offsets inside a buffer) ----
-    const int aoff = (G::x_rows + sg * 16 + lo) * RB + hi * 8;   // A: t[slot lo][5p + 4j + hi]
+    // The MFMA's 16 rows are 8 slots x {real, imaginary part of the coefficient}: row 2 s + c.  The accumulators then hold, per
+    // lane, (P, Q) of a slot in neighbouring registers -- C/D row 4 hi + r = slot 2 hi + (r >> 1), part r & 1 --, which is what
+    // the packed tap-16 products write and what makes (re, im) of every output neighbours further down.  A wave's 16 slots
+    // are two such half-groups (g = 0, 1) that share the B operand.
+    const int aoff = (G::x_rows + sg * 16 + (lo >> 1)) * RB + hi * 8 + (lo & 1) * 4;   // A: part lo & 1 of t[slot 8 g + (lo >> 1)][5p + 4j + hi]
     const int boff = (tg * 16 + lo) * RB + hi * 8;               // B: x[segment lo][5p + 4j + hi]
-    const int doff = (G::x_rows + sg * 16 + 4 * hi) * RB;        // tap 16, C/D layout: t[slot 4 hi + r][5p + 16]
+    const int doff = (G::x_rows + sg * 16 + 2 * hi) * RB;        // tap 16, C/D layout: t[slot 8 g + 2 hi + e][5p + 16]
     const int eoff = (tg * 16 + lo) * RB;                        //                     x[segment lo][5p + 16]
     v2f hA[4];                                                   // taps 4j + hi, j = 0..3, as (h, h) pairs
 #pragma unroll
@@ -153,23 +164,22 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     // All vector arithmetic below is written in packed form (v_pk_mul/add/fma_f32 on register pairs): the f32 MFMA and
     // the vector ALU do not overlap (measured), so beside MFMAs a wave's vector instructions issue alone, at
     // 4 cycles each whether packed or not.
-    struct Ops { v2f t[4], x[4], tr16[2], ti16[2], x16; };
-    struct Acc { v4f Pr, Pi, Qr, Qi; };
+    struct Ops { float ta[2][4]; v2f x[4], t16[4], x16; };     // A operands [g][j]; B = x[j]; tap 16: t16[2 g + e], x16
+    struct Acc { v4f Dr[2], Di[2]; };                           // [g]: A_g x (h xr), A_g x (h xi): (P, Q) of slots 8 g + 2 hi, + 1
     Ops ops;
     Acc acc;
-    // stage-2 accumulators: output (s + dd) & 3 of super-step s; 8 packed values over the lane's slots r = (0,1) and (2,3):
-    // [0,1] re of channel A, [2,3] im of A, [4,5] re of channel B, [6,7] im of B
+    // stage-2 accumulators: output (s + dd) & 3 of super-step s; [4 g + 2 e + A/B] = (re, im) of that channel
     v2f acc2[4][8];
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int i = 0; i < 8; i++) acc2[q][i] = v2f{0.f, 0.f};
 
-    // (volatile: the operand reads stay single ds_read_b64 -- 32 lanes per LDS cycle on 64 banks, which the row pitch makes
+    // LDS pointers in their own address space: every operand address is one per-lane base register + an immediate.
+    // (volatile: the 8-byte operand reads stay single ds_read_b64 -- 32 lanes per LDS cycle on 64 banks, which the row pitch makes
     // conflict-free; merged into ds_read2_b64 they are served 16 lanes at a time on 32 banks: half the rate, and two-way conflicts)
-    // LDS pointers in their own address space: every operand address is one per-lane base register + an immediate
     typedef const volatile __attribute__((address_space(3))) v2f lds_cv2f;
-    typedef const __attribute__((address_space(3))) float lds_cf;
+    typedef const volatile __attribute__((address_space(3))) float lds_cvf;
     typedef const __attribute__((address_space(3))) char lds_cc;
     lds_cc *const lbase = (lds_cc *)(uint32_t)(uintptr_t)lds_m;
     lds_cc *const la = lbase + aoff, *const lb = lbase + boff, *const ld = lbase + doff, *const le = lbase + eoff;
@@ -177,36 +187,31 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         const int bo = bi * G::buf_bytes;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            o.t[j] = *(lds_cv2f *)(la + bo + (5 * ph + 4 * j) * 8);
+            o.ta[0][j] = *(lds_cvf *)(la + bo + (5 * ph + 4 * j) * 8);
+            o.ta[1][j] = *(lds_cvf *)(la + bo + 8 * RB + (5 * ph + 4 * j) * 8);
             o.x[j] = *(lds_cv2f *)(lb + bo + (5 * ph + 4 * j) * 8);
         }
         o.x16 = *(lds_cv2f *)(le + bo + (5 * ph + 16) * 8);
-        // tap 16 of slots (4 hi, 4 hi + 1) and (4 hi + 2, 4 hi + 3): real parts together, imaginary parts together (ds_read2_b32)
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            lds_cf *r0 = (lds_cf *)(ld + bo + (2 * rr) * RB + (5 * ph + 16) * 8);
-            lds_cf *r1 = (lds_cf *)(ld + bo + (2 * rr + 1) * RB + (5 * ph + 16) * 8);
-            o.tr16[rr] = v2f{r0[0], r1[0]};
-            o.ti16[rr] = v2f{r0[1], r1[1]};
-        }
+        for (int i = 0; i < 4; i++) o.t16[i] = *(lds_cv2f *)(ld + bo + (8 * (i >> 1) + (i & 1)) * RB + (5 * ph + 16) * 8);
     };
     auto mfma_phase = [&](const Ops &o, Acc &c) {
+        // tap 16 starts the accumulators: (tr, ti) of a slot times h16 xr resp. h16 xi = the slot's (P, Q) pair
         const v2f xh = o.x16 * v2f{h16, h16};
         const v2f xr = v2f{xh.x, xh.x}, xi = v2f{xh.y, xh.y};
-        const v2f pr0 = o.tr16[0] * xr, pr1 = o.tr16[1] * xr, pi0 = o.tr16[0] * xi, pi1 = o.tr16[1] * xi;
-        const v2f qr0 = o.ti16[0] * xr, qr1 = o.ti16[1] * xr, qi0 = o.ti16[0] * xi, qi1 = o.ti16[1] * xi;
-        c.Pr = v4f{pr0.x, pr0.y, pr1.x, pr1.y};
-        c.Pi = v4f{pi0.x, pi0.y, pi1.x, pi1.y};
-        c.Qr = v4f{qr0.x, qr0.y, qr1.x, qr1.y};
-        c.Qi = v4f{qi0.x, qi0.y, qi1.x, qi1.y};
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const v2f r0 = o.t16[2 * g] * xr, r1 = o.t16[2 * g + 1] * xr, i0 = o.t16[2 * g] * xi, i1 = o.t16[2 * g + 1] * xi;
+            c.Dr[g] = v4f{r0.x, r0.y, r1.x, r1.y};
+            c.Di[g] = v4f{i0.x, i0.y, i1.x, i1.y};
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const v2f t = o.t[j] * hA[j];
-            const v2f x = o.x[j];
-            c.Pr = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, x.x, c.Pr, 0, 0, 0);
-            c.Pi = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, x.y, c.Pi, 0, 0, 0);
-            c.Qr = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, x.x, c.Qr, 0, 0, 0);
-            c.Qi = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, x.y, c.Qi, 0, 0, 0);
+            const v2f x = o.x[j] * hA[j];                        // the tap rides on the B operand (shared by both half-groups)
+            c.Dr[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ta[0][j], x.x, c.Dr[0], 0, 0, 0);
+            c.Di[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ta[0][j], x.y, c.Di[0], 0, 0, 0);
+            c.Dr[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ta[1][j], x.x, c.Dr[1], 0, 0, 0);
+            c.Di[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ta[1][j], x.y, c.Di[1], 0, 0, 0);
         }
     };
 
@@ -224,27 +229,22 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         if (body < 0 || !seg_live) return;
         const uint32_t at = ylane + (uint32_t)(2 * body + h) * SPW * 2;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            *reinterpret_cast<v4f *>(y2_out + (size_t)(yrow[2 * r] + at)) =
-                v4f{stage[0][r >> 1][r & 1], stage[0][2 + (r >> 1)][r & 1], stage[1][r >> 1][r & 1], stage[1][2 + (r >> 1)][r & 1]};
-            *reinterpret_cast<v4f *>(y2_out + (size_t)(yrow[2 * r + 1] + at)) =
-                v4f{stage[0][4 + (r >> 1)][r & 1], stage[0][6 + (r >> 1)][r & 1], stage[1][4 + (r >> 1)][r & 1], stage[1][6 + (r >> 1)][r & 1]};
-        }
+        for (int i = 0; i < 8; i++)
+            *reinterpret_cast<v4f *>(y2_out + (size_t)(yrow[i] + at)) = v4f{stage[0][i].x, stage[0][i].y, stage[1][i].x, stage[1][i].y};
     };
     // combinations + stage 2 for stage-1 output P20 (0..19) of a body
     auto post = [&](auto p20_tag, const Acc &c) {
         constexpr int P20 = decltype(p20_tag)::value;
+        // channel A = the slot's own table: (Pr - Qi) + j (Pi + Qr); channel B = its conjugate: (Pr + Qi) + j (Pi - Qr)
         v2f Y[8];
-        const v2f pr0 = v2f{c.Pr[0], c.Pr[1]}, pr1 = v2f{c.Pr[2], c.Pr[3]}, pi0 = v2f{c.Pi[0], c.Pi[1]}, pi1 = v2f{c.Pi[2], c.Pi[3]};
-        const v2f qr0 = v2f{c.Qr[0], c.Qr[1]}, qr1 = v2f{c.Qr[2], c.Qr[3]}, qi0 = v2f{c.Qi[0], c.Qi[1]}, qi1 = v2f{c.Qi[2], c.Qi[3]};
-        Y[0] = pr0 - qi0;        // channel A = the slot's own table: (Pr - Qi) + j (Pi + Qr)
-        Y[1] = pr1 - qi1;
-        Y[2] = pi0 + qr0;
-        Y[3] = pi1 + qr1;
-        Y[4] = pr0 + qi0;        // channel B = its conjugate:        (Pr + Qi) + j (Pi - Qr)
-        Y[5] = pr1 + qi1;
-        Y[6] = pi0 - qr0;
-        Y[7] = pi1 - qr1;
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float Pr = c.Dr[g][2 * e], Qr = c.Dr[g][2 * e + 1], Pi = c.Di[g][2 * e], Qi = c.Di[g][2 * e + 1];
+                Y[4 * g + 2 * e] = v2f{Pr - Qi, Pi + Qr};
+                Y[4 * g + 2 * e + 1] = v2f{Pr + Qi, Pi - Qr};
+            }
         // stage-2 output j (absolute) has the stage-1 outputs 5j-14 .. 5j+4 as its window (S::addSample fires on every
         // 5th input, msd.hpp:228-247).  Inside a body, input u = P20 % 5 of super-step s = P20 / 5 is element 14 + u - 5 dd
         // of the window of output s + dd: output s + 3 starts at u = 1 (element 0), output s completes at u = 4 (element 18)
@@ -303,15 +303,21 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
                 post(std::integral_constant<int, P20>{}, acc);
                 __builtin_amdgcn_sched_barrier(0);
             };
-            auto run_half = [&](auto h_tag) {
+            // from6: the warm-up body's first half.  Stage 2's first real output has the stage-1 outputs from phase 6 of the
+            // warm-up body on as its window: phases 0..5 of that body are nobody's input and are skipped.
+            auto run_half = [&](auto h_tag, const bool from6) {
                 constexpr int H = decltype(h_tag)::value;
-                load_ops(H, 0, ops);
-                window(std::integral_constant<int, H * 10 + 0>{});
-                window(std::integral_constant<int, H * 10 + 1>{});
-                window(std::integral_constant<int, H * 10 + 2>{});
-                window(std::integral_constant<int, H * 10 + 3>{});
-                window(std::integral_constant<int, H * 10 + 4>{});
-                window(std::integral_constant<int, H * 10 + 5>{});
+                if (!from6) {
+                    load_ops(H, 0, ops);
+                    window(std::integral_constant<int, H * 10 + 0>{});
+                    window(std::integral_constant<int, H * 10 + 1>{});
+                    window(std::integral_constant<int, H * 10 + 2>{});
+                    window(std::integral_constant<int, H * 10 + 3>{});
+                    window(std::integral_constant<int, H * 10 + 4>{});
+                    window(std::integral_constant<int, H * 10 + 5>{});
+                } else {
+                    load_ops(H, 6, ops);
+                }
                 window(std::integral_constant<int, H * 10 + 6>{});
                 window(std::integral_constant<int, H * 10 + 7>{});
                 window(std::integral_constant<int, H * 10 + 8>{});
@@ -319,8 +325,8 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
             };
             // (a wave whose segment group lies past the end of the data only keeps the workgroup's barriers and its share of the DMAs)
             if (seg_live) {
-                if (half == 0) run_half(std::integral_constant<int, 0>{});
-                else run_half(std::integral_constant<int, 1>{});
+                if (half == 0) run_half(std::integral_constant<int, 0>{}, TRIM && b == 0);
+                else run_half(std::integral_constant<int, 1>{}, false);
             }
         }
     }
