@@ -47,6 +47,8 @@ def parse_args(argv=None):
     ap.add_argument("--matrix", type=int, default=0, help="tuning.matrix_pipe: 0 auto, 1 vector kernels only, 2 require k_stage12m (mixer + stage 1 on the f32 matrix pipe)")
     ap.add_argument("--mgs", type=int, default=0, help="tuning.m_slot_groups (k_stage12m workgroup shape), 0 auto")
     ap.add_argument("--mgt", type=int, default=0, help="tuning.m_seg_groups, 0 auto")
+    ap.add_argument("--bg-tail", type=int, default=0, help="tuning.bg_tail: 0 auto, 1 tail stages after the stage-1/2 kernel, 2 require k_tail_bg beside it")
+    ap.add_argument("--bg-wgs", type=int, default=0, help="tuning.bg_wgs: workgroups of k_tail_bg, 0 = one per CU")
     ap.add_argument("--tail-tile", type=int, default=0, help="tuning.tail_tile (final outputs per workgroup of the separate tail kernel), 0 auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
@@ -343,9 +345,9 @@ def main():
         ring = torch.from_numpy(host).cuda()
 
     tuning = None
-    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile:
+    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile or args.bg_tail or args.bg_wgs:
         tuning = {"fused_tail": args.fused, "pair_lanes": args.pair, "matrix_pipe": args.matrix, "m_slot_groups": args.mgs, "m_seg_groups": args.mgt,
-                  "tail_tile": args.tail_tile}
+                  "tail_tile": args.tail_tile, "bg_tail": args.bg_tail, "bg_wgs": args.bg_wgs}
     fused_seen = {}
     pair_seen = {}
     matrix_seen = {}

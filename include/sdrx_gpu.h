@@ -105,6 +105,11 @@ typedef struct {
     uint32_t matrix_pipe;    /* mixer + stage 1 of the 10 MS/s chain on the f32 matrix pipe (k_stage12m: exact fp32
                                 fma chains in another summation order -- the one choice here whose outputs differ
                                 from the others', by rounding only): 0 = auto, 1 = never, 2 = require            */
+    uint32_t bg_tail;        /* banks on the matrix pipe: the tail stages run BESIDE the stage-1/2 kernel of the same block (one
+                                persistent low-footprint workgroup per CU takes the channels whose slot groups are complete;
+                                device and pinned entries; same outputs bit for bit): 0 = auto (off: no gain measured yet),
+                                1 = never, 2 = require */
+    uint32_t bg_wgs;         /*   workgroups of that background kernel, 0 = auto (one per CU) */
     uint32_t m_slot_groups;  /* k_stage12m workgroup = m_slot_groups x m_seg_groups tiles (waves) of 16 channel    */
     uint32_t m_seg_groups;   /*   pairs x 16 time segments: (2,2), (4,2) or (2,4); 0 = auto                        */
 } sdrxgpu_tuning;
@@ -176,6 +181,7 @@ typedef struct {
     uint32_t k12_bodies;       /*   bodies per lane */
     uint32_t matrix_pipe;      /* 1: mixer + stage 1 run on the f32 matrix pipe (k_stage12m) */
     uint32_t m_slots;          /*   its channel-pair slots (pairs + channels without partner + padding) */
+    uint32_t bg_tail;          /* 1: tail stages beside the stage-1/2 kernel (k_tail_bg) on the device / pinned entries */
 } sdrxgpu_bank_info;
 
 /* Fill the AGC / LfAGC parameter blocks as sdrx configures them per channel

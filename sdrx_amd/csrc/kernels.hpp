@@ -290,6 +290,7 @@ struct Stage12Args {
     int c0;
     int n_y3;
     int seam_stride;        // float2 per channel of the seam buffer: [range][2][TA-1] (first / last TA-1 outputs of each range)
+    unsigned *done;         // k_stage12m beside k_tail_bg: [set] += 1 per finished item (after an agent-scope release); nullptr: off
 };
 
 // LDS tile geometry.  A wave's 64 lanes are CPW channels x SPW = 64/CPW time segments (lane =
@@ -1031,6 +1032,11 @@ struct TailArgs {
     // body-major storage of the new stage-2 outputs (see k_stage12): geometry of the launch that wrote them
     int y2b, seg_len, ph_len, spw_shift, spw, nb, P;       // seg_len = bps*Y2B, ph_len = nb*Y2B
     int y2b_shift;          // log2(y2b)
+    // overlapped tail (k_tail_bg beside k_stage12m, then this kernel for what is left): channels are taken from order[first ..],
+    // first = min(*next, n_units), instead of n_ch-1 downwards; nullptr: off
+    const int *order;
+    const unsigned *next;
+    int n_units;
     int half_split;         // 1: written by k_stage12m -- a body's four outputs of a segment lie as two pairs, one in each of the
                             // body's two half-body rows: [time-wave][2 body + h][segment][2] (kernels_mfma.hpp); y2b is 4
     float rcp_seg_len, rcp_ph_len, rcp_y2b;
@@ -1198,19 +1204,11 @@ __device__ __forceinline__ int y2_group_index(const TailArgs &a, int j)
     return y2_storage_index(a, j);
 }
 
+// one (channel, tile) of k_tail_s: everything a workgroup of that kernel does (k_tail_bg walks channels with it)
 template <int MA, int TA, int MB, int TB>
-__global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
+__device__ __forceinline__ void tail_s_unit(const TailArgs &a, const int ch, const int q, float2 *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
     constexpr bool HAS_A = MA > 0;
-
-    const int xcd = blockIdx.x & 7;
-    const int qq = blockIdx.x >> 3;
-    const int q = qq % a.n_tiles;
-    const int chf = (qq / a.n_tiles) * 8 + xcd;
-    if (chf >= a.n_ch) return;
-    const int ch = a.n_ch - 1 - chf;
-    if (ch < a.ch_lo) return;
     const int tid = threadIdx.x;
     const float2 *__restrict__ ynew = a.y2_new + (size_t)ch * a.y2_stride;
     const float2 *__restrict__ hin = a.hist_in + (size_t)ch * a.hist;
@@ -1293,6 +1291,92 @@ __global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
         if (a.iq_keep) a.iq_keep[(size_t)ch * a.keep_stride + s0 + tid] = o;
     }
 }
+
+template <int MA, int TA, int MB, int TB>
+__global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int xcd = blockIdx.x & 7;
+    const int qq = blockIdx.x >> 3;
+    const int q = qq % a.n_tiles;
+    const int chf = (qq / a.n_tiles) * 8 + xcd;
+    if (chf >= a.n_ch) return;
+    int ch;
+    if (a.order) {                                         // what k_tail_bg left: units first .. n_units-1 of its list, from the
+        const int first = (int)min(*a.next, (unsigned)a.n_units);   // last one down (the rows written last are the ones still cached)
+        if (a.n_units - 1 - chf < first) return;
+        ch = a.order[a.n_units - 1 - chf];
+    } else {
+        ch = a.n_ch - 1 - chf;
+        if (ch < a.ch_lo) return;
+    }
+    tail_s_unit<MA, TA, MB, TB>(a, ch, q, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tail_bg: the tail stages BESIDE the stage-1/2 kernel of the same block.  One persistent workgroup per CU (launched first, so
+// it has its place; 18 KB of LDS and ~50 VGPRs fit beside two workgroups of k_stage12m) takes channels from `order` (the slot
+// order k_stage12m works through) one after the other, waits until the channel's set of slot groups is complete -- k_stage12m
+// adds 1 to done[set] per finished item, after its stores have been released at agent scope --, and runs the channel's tiles
+// through tail_s_unit.  It stops claiming when `stop` is raised (by a one-thread kernel behind k_stage12m on its stream); what is
+// left then is k_tail_s's (TailArgs.order).  Measured beside a kernel of k_stage12m's shape (tools/ubench_corun.hip): one such
+// workgroup per CU streams 3.1 TB/s and costs the compute kernel 7.5 %; two per CU cost it 50 %.
+// ------------------------------------------------------------------------------------------
+struct BgArgs {
+    const unsigned *done;    // [sets] items of k_stage12m finished, ever (never reset)
+    unsigned target;         // ... a set of THIS block is complete at
+    unsigned *next;          // next unit to claim (reset to 0 per block)
+    const int *stop;         // != 0: claim nothing more
+    const int *order;        // [n_units] channel of unit i
+    const int *set_of;       // [n_units] its set
+    int n_units;
+};
+
+template <int MA, int TA, int MB, int TB>
+__global__ __launch_bounds__(256) void k_tail_bg(const TailArgs a, const BgArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    __shared__ int s_idx;
+    const int tid = threadIdx.x;
+#ifndef SDRX_BG_PRIO
+#define SDRX_BG_PRIO 3
+#endif
+    // (few instructions, and every one of them stands between a memory round trip and the next: they go first)
+    __builtin_amdgcn_s_setprio(SDRX_BG_PRIO);
+    for (;;) {
+        if (tid == 0) {
+            int idx = -1;
+            if (!__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                idx = (int)__hip_atomic_fetch_add(g.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (idx >= g.n_units) idx = -1;
+            }
+            if (idx >= 0) {
+                // the unit's set complete?  (stop raised = the stage-1/2 kernel has ended: every set is.)  Bounded: ~2 s of
+                // 100 MHz ticks, then on regardless -- a hang is worse than a wrong block
+                const unsigned *d = g.done + g.set_of[idx];
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while ((int)(__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) {
+                    if (__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+                    __builtin_amdgcn_s_sleep(32);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 forgets what it held of the rows
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            s_idx = idx;
+        }
+        __syncthreads();
+        const int idx = s_idx;
+        if (idx < 0) break;
+        const int ch = g.order[idx];
+        for (int q = 0; q < a.n_tiles; q++) {
+            tail_s_unit<MA, TA, MB, TB>(a, ch, q, smem);
+            __syncthreads();                               // the tile's LDS is free again (and s_idx may be rewritten after the last one)
+        }
+    }
+}
+
+__global__ void k_bg_set(unsigned *next, int *stop, const int reset) { if (reset) *next = 0u; *stop = reset ? 0 : 1; }
 
 // ------------------------------------------------------------------------------------------
 // k_tail4: what follows a k_stage12 with fused stage 3.  One workgroup per channel:

@@ -49,17 +49,14 @@ struct TileGeomM {
     static constexpr int pairs_per_wave = (pairs + waves - 1) / waves;
 };
 
-// 1: the first six phases of a lane's warm-up body are skipped (nobody's input; -1.5 % on the launch although the second
-// path through the half-body costs registers: 256 VGPRs and a few spills instead of 209)
-#ifndef SDRX_M_TRIM
-#define SDRX_M_TRIM 1
-#endif
 struct Stage12mTaps {
     float h1[17];
     float h2[10];       // h2[0 .. 9]; h2[18 - e] = h2[e] (the reference reads that half only, msd.hpp:309-331): 10 scalar register pairs, not 19
 };
 
-template <int GS, int GT>
+// TRIM: skip the first six phases of a lane's warm-up body (nobody's input): -1.5 % on the launch, but the second path through the
+// half-body costs registers -- 256 VGPRs and a few spills instead of 209; the launch beside k_tail_bg needs the 209.
+template <int GS, int GT, bool TRIM>
 __global__ __launch_bounds__(64 * GS * GT, 2)
 void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
                 const Stage12Args a, const PairArgs pa, const Stage12mTaps taps)
@@ -67,7 +64,6 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     using G = TileGeomM<GS, GT>;
     constexpr int SB = 100, Y2B = 4, SPW = 16;
     constexpr int RB = G::row_bytes;
-    constexpr bool TRIM = SDRX_M_TRIM != 0;
     extern __shared__ __attribute__((aligned(16))) char lds_m[];
 
     const int tid = threadIdx.x;
@@ -89,7 +85,16 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     const int gq = wtm / a.P, p = wtm - gq * a.P;
     const int bps = a.nb * a.P;
     const int g_first = gq * GT;                            // first segment group of the workgroup
-    if ((g_first * SPW * bps + a.nb * p) * Y2B >= a.n_y2_new) continue;
+    // (beside k_tail_bg every item of a set reports, also one that has nothing to do)
+    // (the item's stores are write-through then -- sc1, store_staged -- and every wave has waited for its own before the
+    // barrier in front of this: no release fence, which would write back the whole XCD's dirty lines once per item)
+    auto report = [&]() {
+        if (tid == 0) __hip_atomic_fetch_add(a.done + cgm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if ((g_first * SPW * bps + a.nb * p) * Y2B >= a.n_y2_new) {
+        if (a.done) report();
+        continue;
+    }
 
     // ---- what this lane stores: slots 4*hi + r of the wave's group, both channels of each.  A place without channel
     // (empty slot, no partner) stores into the spare row behind the last channel's: no branch around any store ----
@@ -228,6 +233,14 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     auto store_staged = [&](int body, int h) {
         if (body < 0 || !seg_live) return;
         const uint32_t at = ylane + (uint32_t)(2 * body + h) * SPW * 2;
+        if (a.done) {       // beside k_tail_bg: write-through, so that a counter behind vmcnt(0) + barrier publishes the rows (MI355X_MICROARCH.md, valid forms)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const v4f v = v4f{stage[0][i].x, stage[0][i].y, stage[1][i].x, stage[1][i].y};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(y2_out + (size_t)(yrow[i] + at)), "v"(v) : "memory");
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++)
             *reinterpret_cast<v4f *>(y2_out + (size_t)(yrow[i] + at)) = v4f{stage[0][i].x, stage[0][i].y, stage[1][i].x, stage[1][i].y};
@@ -331,6 +344,11 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         }
     }
     store_staged(a.nb - 1, 1);                                  // the last half-body's outputs
+    if (a.done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's stores have left it ...
+        __syncthreads();
+        report();                                               // ... then one lane releases them and counts the item
+    }
     // (the next item's first rows go to buffer 0, which every wave left before the barrier of the last half-body)
     }
 }

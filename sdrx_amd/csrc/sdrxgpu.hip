@@ -300,34 +300,39 @@ struct K12mLaunch {
 static bool k12m_geometry_compiled(int GS, int GT) { return (GS == 2 && GT == 2) || (GS == 4 && GT == 2) || (GS == 2 && GT == 4); }
 static size_t k12m_lds_bytes(int GS, int GT) { return 2 * (size_t)(16 * GS + 16 * GT) * 528; }
 
-template <int GS, int GT>
+template <int GS, int GT, bool TRIM>
 static hipError_t launch_k12m_one(const K12mLaunch &M, const Stage12mTaps &taps, hipStream_t s)
 {
-    static_assert(2 * TileGeomM<GS, GT>::buf_bytes <= 160 * 1024, "two tile buffers must fit the LDS");
     using TG = TileGeomM<GS, GT>;
-    hipLaunchKernelGGL((k_stage12m<GS, GT>), dim3(M.L.grid), dim3(64 * GS * GT), 2 * TG::buf_bytes, s,
+    static_assert(2 * TG::buf_bytes <= 160 * 1024, "two tile buffers must fit the LDS");
+    hipLaunchKernelGGL((k_stage12m<GS, GT, TRIM>), dim3(M.L.grid), dim3(64 * GS * GT), 2 * TG::buf_bytes, s,
                        M.L.x, M.L.tables, M.L.y2, M.L.args, M.pa, taps);
     return hipGetLastError();
 }
 
-static hipError_t launch_k12m(const K12mLaunch &M, hipStream_t s)
+// `lean`: the 209-VGPR build (whole warm-up body) that leaves a SIMD room for a wave of k_tail_bg beside two of its own
+static hipError_t launch_k12m(const K12mLaunch &M, bool lean, hipStream_t s)
 {
     Stage12mTaps taps{};
     for (int i = 0; i < 17; i++) taps.h1[i] = M.L.h1[i < 9 ? i : 16 - i];     // (the reference reads h[0 .. half] only, msd.hpp:309-331)
     for (int i = 0; i < 10; i++) taps.h2[i] = M.L.h2[i];
-    if (M.GS == 2 && M.GT == 2) return launch_k12m_one<2, 2>(M, taps, s);
-    if (M.GS == 4 && M.GT == 2) return launch_k12m_one<4, 2>(M, taps, s);
-    if (M.GS == 2 && M.GT == 4) return launch_k12m_one<2, 4>(M, taps, s);
+    if (M.GS == 2 && M.GT == 2) return lean ? launch_k12m_one<2, 2, false>(M, taps, s) : launch_k12m_one<2, 2, true>(M, taps, s);
+    if (M.GS == 4 && M.GT == 2) return lean ? launch_k12m_one<4, 2, false>(M, taps, s) : launch_k12m_one<4, 2, true>(M, taps, s);
+    if (M.GS == 2 && M.GT == 4) return lean ? launch_k12m_one<2, 4, false>(M, taps, s) : launch_k12m_one<2, 4, true>(M, taps, s);
     return hipErrorInvalidValue;
 }
 
 static hipError_t k12m_set_attributes(int GS, int GT)
 {
     const int n = (int)k12m_lds_bytes(GS, GT);
-    if (GS == 2 && GT == 2) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    if (GS == 4 && GT == 2) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    if (GS == 2 && GT == 4) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    return hipErrorInvalidValue;
+    const void *f[2] = {nullptr, nullptr};
+    if (GS == 2 && GT == 2) { f[0] = reinterpret_cast<const void *>(&k_stage12m<2, 2, true>); f[1] = reinterpret_cast<const void *>(&k_stage12m<2, 2, false>); }
+    if (GS == 4 && GT == 2) { f[0] = reinterpret_cast<const void *>(&k_stage12m<4, 2, true>); f[1] = reinterpret_cast<const void *>(&k_stage12m<4, 2, false>); }
+    if (GS == 2 && GT == 4) { f[0] = reinterpret_cast<const void *>(&k_stage12m<2, 4, true>); f[1] = reinterpret_cast<const void *>(&k_stage12m<2, 4, false>); }
+    if (!f[0]) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(f[0], hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    if (e == hipSuccess) e = hipFuncSetAttribute(f[1], hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    return e;
 }
 
 struct K12Entry {
@@ -460,6 +465,15 @@ struct sdrxgpu_bank {
     int2 *d_slots_m = nullptr, *d_slots_mp = nullptr;  // partners from the whole bank / from inside each host part
     int n_slots_m = 0, n_slots_mp = 0, n_pairs_m = 0;
     std::vector<int> part_gm;                         // set boundaries of the host parts
+    // tail stages beside the stage-1/2 kernel of the same block (k_tail_bg, kernels.hpp): whole-bank launches of the device /
+    // pinned entries.  order / set_of: the channels in the order k_stage12m's slot list works through, and their sets
+    bool bg_tail = false;
+    hipStream_t stream_bg = nullptr;
+    hipEvent_t ev_bg_go = nullptr, ev_bg_done = nullptr;
+    unsigned *d_bg_done = nullptr, *d_bg_next = nullptr;
+    int *d_bg_stop = nullptr, *d_bg_order = nullptr, *d_bg_set_of = nullptr;
+    unsigned bg_target = 0;                           // items per set k_stage12m has reported when the current block is complete
+    int bg_cus = 256;
     bool pair = false, want_pair = false;
     int2 *d_slots = nullptr;
     unsigned char *d_group_conj = nullptr;            // per slot group: conjugate partners (one translator row per slot) or any two channels
@@ -534,6 +548,14 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_seam);
     (void)hipFree(b->d_slots);
     (void)hipFree(b->d_slots_m);
+    (void)hipFree(b->d_bg_done);
+    (void)hipFree(b->d_bg_next);
+    (void)hipFree(b->d_bg_stop);
+    (void)hipFree(b->d_bg_order);
+    (void)hipFree(b->d_bg_set_of);
+    if (b->stream_bg) (void)hipStreamDestroy(b->stream_bg);
+    if (b->ev_bg_go) (void)hipEventDestroy(b->ev_bg_go);
+    if (b->ev_bg_done) (void)hipEventDestroy(b->ev_bg_done);
     (void)hipFree(b->d_group_conj);
     (void)hipFree(b->d_keep);
     (void)hipFree(b->d_audio_keep);
@@ -1091,6 +1113,53 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "k_stage12m set-up failed: %s", hipGetErrorString(e));
         }
+        // Tail stages beside the stage-1/2 kernel (k_tail_bg): the 10 MS/s chain's compiled tail, not pipelined
+        {
+            const bool can = cfg->n_stages == 4 && b->m[2] == 5 && b->ntaps[2] == 21 && b->m[3] == 5 && b->ntaps[3] == 67 && !b->pipelined &&
+                             !b->tail_generic;
+            if (tune.bg_tail > 2 || (tune.bg_tail == 2 && !can)) {
+                free_bank(b);
+                return fail(tune.bg_tail > 2 ? SDRXGPU_ERR_INVALID_ARG : SDRXGPU_ERR_UNSUPPORTED,
+                            "bank_create: tuning.bg_tail %u (0..2; 2 needs the 10 MS/s chain's tail (5,21)(5,67), no pipelining, no generic tail)", tune.bg_tail);
+            }
+            // (not automatic: measured 0.891 against 0.887 ms per 10 000-channel block -- k_tail_bg gets through a third of the
+            // channels while k_stage12m runs, which takes 9 % longer beside it)
+            b->bg_tail = can && tune.bg_tail == 2;
+        }
+        if (b->bg_tail) {
+            std::vector<int> order, set_of;
+            for (size_t i = 0; i < slots_all.size(); i++) {
+                if (slots_all[i].x >= 0) { order.push_back(slots_all[i].x); set_of.push_back((int)(i / set)); }
+                if (slots_all[i].x >= 0 && slots_all[i].y >= 0) { order.push_back(slots_all[i].y); set_of.push_back((int)(i / set)); }
+            }
+            const size_t n_sets = slots_all.size() / set + 8;
+            if (order.size() != b->n_ch) {
+                free_bank(b);
+                return fail(SDRXGPU_ERR_HIP, "internal: %zu channels in the slot list of a bank of %u", order.size(), b->n_ch);
+            }
+            if ((rc2 = dev_alloc(b, (void **)&b->d_bg_done, n_sets * sizeof(unsigned))) ||
+                (rc2 = dev_alloc(b, (void **)&b->d_bg_next, 64)) || (rc2 = dev_alloc(b, (void **)&b->d_bg_stop, 64)) ||
+                (rc2 = dev_alloc(b, (void **)&b->d_bg_order, order.size() * sizeof(int))) ||
+                (rc2 = dev_alloc(b, (void **)&b->d_bg_set_of, set_of.size() * sizeof(int)))) {
+                free_bank(b);
+                return rc2;
+            }
+            e = hipMemset(b->d_bg_done, 0, n_sets * sizeof(unsigned));
+            if (e == hipSuccess) e = hipMemset(b->d_bg_next, 0, 64);
+            if (e == hipSuccess) e = hipMemset(b->d_bg_stop, 0, 64);
+            if (e == hipSuccess) e = hipMemcpy(b->d_bg_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(b->d_bg_set_of, set_of.data(), set_of.size() * sizeof(int), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream_bg, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_bg_go, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_bg_done, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_bg<5, 21, 5, 67>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->tail_lds);
+            if (e != hipSuccess) {
+                free_bank(b);
+                return fail(SDRXGPU_ERR_HIP, "k_tail_bg set-up failed: %s", hipGetErrorString(e));
+            }
+            b->bg_cus = tune.bg_wgs ? (int)std::min<uint32_t>(tune.bg_wgs, 4096u) : (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+            b->bg_target = 0;
+        }
     }
 
     if (cfg->stream) {
@@ -1351,6 +1420,7 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
     info->k12_bodies = (uint32_t)b->nb;
     info->matrix_pipe = b->mfma ? 1u : 0u;
     info->m_slots = b->mfma ? (uint32_t)b->n_slots_m : 0u;
+    info->bg_tail = b->bg_tail ? 1u : 0u;
     return SDRXGPU_OK;
 }
 
@@ -1533,7 +1603,7 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
         M.pa.lds_bytes = (int)k12m_lds_bytes(b->mGS, b->mGT);
         if ((uint64_t)(b->n_ch + 1) * (uint64_t)b->y2_stride >= (1ull << 32))
             return fail(SDRXGPU_ERR_HIP, "internal: stage-2 scratch of %u x %d entries exceeds k_stage12m's 32-bit row offsets", b->n_ch, b->y2_stride);
-        HIPCHK(launch_k12m(M, st));
+        HIPCHK(launch_k12m(M, M.L.args.done != nullptr, st));        // (beside k_tail_bg: the build that leaves it room)
         return SDRXGPU_OK;
     }
     if (!b->pair) {
@@ -1625,6 +1695,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         L.y3 = nullptr;
         L.seam = nullptr;
         a.seam_stride = 0;
+        a.done = nullptr;
         L.W = b->W;
         L.CPW = b->CPW;
         L.grid = a.n_cgx * a.n_wt;
@@ -1740,8 +1811,11 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
 // Tail stage(s) + AGC/demod of a prepared job on the bank's stream, outputs to the given device pointers.
 // [ch_lo, ch_hi): the channels of this launch (ch_hi < 0: the whole bank); `last`: the last (or only) part of the chunk --
 // what concerns the whole bank (history copy, squelch / audio FIR / mix-down, the output count) happens with it.
+// `overlap`: the job's stage-1/2 kernel has NOT been launched yet (launch_stage12 with defer); it is launched here, on the bank's
+// stream, behind k_tail_bg on the side stream -- the tail stages of every channel whose slot groups are complete run beside it --,
+// and k_tail_s then takes what is left (whole bank, banks with bg_tail only).
 static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq_out, float *d_audio_out, size_t out_stride,
-                       size_t out_off, size_t *produced, int ch_lo = 0, int ch_hi = -1, bool last = true)
+                       size_t out_off, size_t *produced, int ch_lo = 0, int ch_hi = -1, bool last = true, bool overlap = false)
 {
     *produced = 0;
     if (!job->valid) return SDRXGPU_OK;
@@ -1795,6 +1869,46 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     } else {
         t.hist_in = b->d_hist[b->hist_cur];
         t.hist_out = b->d_hist[b->hist_cur ^ 1];
+        t.order = nullptr;
+        t.next = nullptr;
+        t.n_units = 0;
+        if (overlap) {
+            const int nparts = (int)b->part_ch.size() - 1;
+            const int n_wt_m = (job->L.args.n_wt / b->P + b->mGT - 1) / b->mGT * b->P;      // items per set of this launch (launch_k12_parts)
+            b->bg_target += (unsigned)n_wt_m;
+            hipLaunchKernelGGL(k_bg_set, dim3(1), dim3(1), 0, b->stream, b->d_bg_next, b->d_bg_stop, 1);    // next = 0, stop = 0
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(b->ev_bg_go, b->stream));
+            HIPCHK(hipStreamWaitEvent(b->stream_bg, b->ev_bg_go, 0));
+            BgArgs g;
+            g.done = b->d_bg_done;
+            g.target = b->bg_target;
+            g.next = b->d_bg_next;
+            g.stop = b->d_bg_stop;
+            g.order = b->d_bg_order;
+            g.set_of = b->d_bg_set_of;
+            g.n_units = (int)b->n_ch;
+            // one workgroup per CU, launched BEFORE the stage-1/2 kernel: it has its place when that kernel's workgroups arrive
+            hipLaunchKernelGGL((k_tail_bg<5, 21, 5, 67>), dim3(b->bg_cus), dim3(256), b->tail_lds, b->stream_bg, t, g);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(b->ev_bg_done, b->stream_bg));
+            job->L.args.done = b->d_bg_done;
+            const int rc12 = launch_k12_parts(b, job, b->stream, 0, nparts);
+            // (whatever happened to that launch: the flag that ends k_tail_bg's waiting always follows)
+            hipLaunchKernelGGL(k_bg_set, dim3(1), dim3(1), 0, b->stream, b->d_bg_next, b->d_bg_stop, 0);    // stop = 1
+            const hipError_t e_stop = hipGetLastError();
+            if (rc12 || e_stop != hipSuccess) {
+                (void)hipStreamWaitEvent(b->stream, b->ev_bg_done, 0);
+                if (rc12) return rc12;
+                HIPCHK(e_stop);
+            }
+            // k_tail_s takes the units from *next on right away (k_tail_bg claims nothing after the flag; a claim that was in
+            // flight makes one channel run twice, to the same bits); k_tail_bg's last channels finish beside it and are waited
+            // for before k_agc reads the rows
+            t.order = b->d_bg_order;
+            t.next = b->d_bg_next;
+            t.n_units = (int)b->n_ch;
+        }
         ProfScope ps(b, SDRXGPU_K_TAIL);
         const dim3 grid(((n_part + 7) / 8 * 8) * t.n_tiles);
         const int mA = t.has_a ? t.mA : 0, tA = t.has_a ? t.tA : 0;
@@ -1811,6 +1925,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             hipLaunchKernelGGL(k_tail, grid, dim3(256), b->tail_lds, b->stream, t);
 #undef SDRX_TAIL_CASE
         HIPCHK(hipGetLastError());
+        if (overlap) HIPCHK(hipStreamWaitEvent(b->stream, b->ev_bg_done, 0));
         if (last) b->hist_cur ^= 1;
     }
 
@@ -1930,9 +2045,15 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
                      size_t out_off, size_t *produced)
 {
     sdrxgpu_bank::TailJob job;
-    int rc = launch_stage12(b, in_len, b->stream, b->d_y2, &job);
+    // banks with bg_tail: the stage-1/2 kernel is launched inside launch_tail, behind the background tail kernel
+    const bool overlap = b->bg_tail;
+    int rc = launch_stage12(b, in_len, b->stream, b->d_y2, &job, overlap);
     if (rc) return rc;
-    return launch_tail(b, &job, d_iq_out, d_audio_out, out_stride, out_off, produced);
+    if (overlap && job.valid && job.t.n_b <= 0) {           // stage-2 outputs but no final output in this call: nothing for a tail to do
+        if ((rc = launch_k12_parts(b, &job, b->stream, 0, (int)b->part_ch.size() - 1))) return rc;
+        return launch_tail(b, &job, d_iq_out, d_audio_out, out_stride, out_off, produced);
+    }
+    return launch_tail(b, &job, d_iq_out, d_audio_out, out_stride, out_off, produced, 0, -1, true, overlap && job.valid);
 }
 
 // Pipelined mode: stage-1/2 of THIS block on stream2, concurrently the tail + AGC of the PREVIOUS block on the
