@@ -8,13 +8,14 @@ j $E/bench.log $P/${T}_bench.json
 j $E/bench_vector.log $P/${T}_bench_vector_kernels.json
 j $E/bench_vector_separate_tail.log $P/${T}_bench_vector_kernels_separate_tail.json
 j $E/bench_rccl_1rank.log $P/${T}_bench_rccl_1rank.json
+j $E/bench_bg_tail.log $P/${T}_bench_bg_tail.json
 j $E/bench_under_rocprof_trace.log $P/${T}_bench_under_rocprof.json
 j $E/bench_under_rocprof_trace_vector.log $P/${T}_bench_under_rocprof_vector_kernels.json
 cp "$(ls -t $E/trace/runc/*_kernel_stats.csv | head -1)" $P/${T}_kernel_stats.csv
 cp "$(ls -t $E/trace_vector/runc/*_kernel_stats.csv | head -1)" $P/${T}_kernel_stats_vector_kernels.csv
 cp $E/pmc_matrix/summary.txt $P/${T}_pmc_summary.txt;                 cp $E/pmc_matrix/traffic.json $P/${T}_traffic.json
 cp $E/pmc_vector/summary.txt $P/${T}_vector_kernels_pmc_summary.txt;  cp $E/pmc_vector/traffic.json $P/${T}_vector_kernels_traffic.json
-cp $E/ubench_valu.txt $P/${T}_ubench_valu.txt; cp $E/ubench_hbm_read.txt $P/${T}_ubench_hbm_read.txt; cp $E/ubench_mfma_fir.txt $P/${T}_ubench_mfma_fir.txt
+cp $E/ubench_valu.txt $P/${T}_ubench_valu.txt; cp $E/ubench_hbm_read.txt $P/${T}_ubench_hbm_read.txt; cp $E/ubench_mfma_fir.txt $P/${T}_ubench_mfma_fir.txt; cp $E/ubench_corun.txt $P/${T}_ubench_corun.txt
 tail -3 $E/gpu_tests.log > $P/${T}_gpu_tests_tail.txt
 python3 - "$T" <<'PY'
 import json, sys
