@@ -297,6 +297,11 @@ struct K12mLaunch {
     int GS, GT;
 };
 
+#ifndef SDRX_BGS_NB
+#define SDRX_BGS_NB 2       // time-wave blocks per chunk of k_tail_bgs (its LDS: 24 + 768 NB + 1 342 entries)
+#endif
+static size_t bgs_lds_bytes() { return (size_t)(24 + 768 * SDRX_BGS_NB + 5 * 255 + 67 + 24) * sizeof(float2); }
+
 static bool k12m_geometry_compiled(int GS, int GT) { return (GS == 2 && GT == 2) || (GS == 4 && GT == 2) || (GS == 2 && GT == 4); }
 static size_t k12m_lds_bytes(int GS, int GT) { return 2 * (size_t)(16 * GS + 16 * GT) * 528; }
 
@@ -1153,6 +1158,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_bg_go, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_bg_done, hipEventDisableTiming);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_bg<5, 21, 5, 67>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->tail_lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_bgs<5, 21, 5, 67, SDRX_BGS_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bgs_lds_bytes());
             if (e != hipSuccess) {
                 free_bank(b);
                 return fail(SDRXGPU_ERR_HIP, "k_tail_bg set-up failed: %s", hipGetErrorString(e));
@@ -1872,6 +1878,10 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         t.order = nullptr;
         t.next = nullptr;
         t.n_units = 0;
+        t.unit_shift = 0;
+        // k_tail_bgs (half channels, streamed) where the scratch has k_stage12m's whole-segment layout, else k_tail_bg (channels, tile by tile)
+        const bool stream_layout = t.half_split && t.P == 1 && t.spw == 16 && t.seg_len == 48 && t.hist % 2 == 0 && t.hist >= 2 && t.hist <= 768;
+        const bool bg_stream = overlap && stream_layout && bgs_lds_bytes() + k12m_lds_bytes(b->mGS, b->mGT) * 2 <= 160 * 1024;
         if (overlap) {
             const int nparts = (int)b->part_ch.size() - 1;
             const int n_wt_m = (job->L.args.n_wt / b->P + b->mGT - 1) / b->mGT * b->P;      // items per set of this launch (launch_k12_parts)
@@ -1887,9 +1897,12 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             g.stop = b->d_bg_stop;
             g.order = b->d_bg_order;
             g.set_of = b->d_bg_set_of;
-            g.n_units = (int)b->n_ch;
+            g.n_units = bg_stream ? 2 * (int)b->n_ch : (int)b->n_ch;
             // one workgroup per CU, launched BEFORE the stage-1/2 kernel: it has its place when that kernel's workgroups arrive
-            hipLaunchKernelGGL((k_tail_bg<5, 21, 5, 67>), dim3(b->bg_cus), dim3(256), b->tail_lds, b->stream_bg, t, g);
+            if (bg_stream)
+                hipLaunchKernelGGL((k_tail_bgs<5, 21, 5, 67, SDRX_BGS_NB>), dim3(b->bg_cus), dim3(256), bgs_lds_bytes(), b->stream_bg, t, g);
+            else
+                hipLaunchKernelGGL((k_tail_bg<5, 21, 5, 67>), dim3(b->bg_cus), dim3(256), b->tail_lds, b->stream_bg, t, g);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(b->ev_bg_done, b->stream_bg));
             job->L.args.done = b->d_bg_done;
@@ -1908,6 +1921,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             t.order = b->d_bg_order;
             t.next = b->d_bg_next;
             t.n_units = (int)b->n_ch;
+            t.unit_shift = bg_stream ? 1 : 0;
         }
         ProfScope ps(b, SDRXGPU_K_TAIL);
         const dim3 grid(((n_part + 7) / 8 * 8) * t.n_tiles);

@@ -3,6 +3,8 @@
 //   mode 0: grid-stride, each thread U x 16-byte loads in flight, persistent grid (G workgroups per CU)
 //   mode 1: one workgroup per 15 KB span (k_tail_s's shape): 256 threads x 4 loads, then exit
 //   mode 2: one workgroup per 100 KB row, chunks of 6 KB, D chunks in flight (k_tail_stream's shape)
+//   mode 3: k_tail_stream's loads exactly: 256 threads, chunks of NB x 6 KB as 8-row x 8-segment pieces, D chunks in flight in registers
+//           (inline-assembly loads, counted waits), 16-byte LDS stores, two barriers per chunk, rows last to first
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +63,63 @@ __global__ __launch_bounds__(192) void k_rows(const v4f *__restrict__ x, size_t 
     if (acc.x == 123.456f) out[0] = acc.y;
 }
 
+template <int NB, int D>
+__global__ __launch_bounds__(256) void k_rows2(const v4f *__restrict__ x, size_t row16, int n_rows, float *out, int lds_pad16)
+{
+    extern __shared__ v4f buf2[];
+    constexpr int NWP = NB * 6, NPC = (NWP + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const v4f *row = x + (size_t)(n_rows - 1 - (int)blockIdx.x) * row16;
+    const int n_chunks = (int)((row16 < 6400 ? row16 : 6400) / (384 * NB));
+    int goff[NPC], loff[NPC];
+#pragma unroll
+    for (int u = 0; u < NPC; u++) {
+        const int w = wave + 4 * u, kb = w / 6, ww = w - 6 * kb;
+        const int r = 8 * (ww >> 1) + (lane & 7), sg = 8 * (ww & 1) + (lane >> 3);
+        goff[u] = w < NWP ? kb * 384 + r * 16 + sg : 0;
+        loff[u] = w < NWP ? kb * 384 + sg * 24 + r : -1;
+    }
+    v4f r[D][NPC];
+    auto fetch = [&](int c, v4f (&q)[NPC]) __attribute__((always_inline)) {
+        c = c < n_chunks ? c : n_chunks - 1;
+#pragma unroll
+        for (int u = 0; u < NPC; u++) {
+            const v4f *p = row + (size_t)c * 384 * NB + goff[u];
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[u]) : "v"(p) : "memory");
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(d, r[d]);
+    v4f acc = {0, 0, 0, 0};
+    for (int c = 0; c < n_chunks; c += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"((D - 1) * NPC) : "memory");
+#pragma unroll
+            for (int u = 0; u < NPC; u++) asm volatile("" : "+v"(r[d][u]));
+#pragma unroll
+            for (int u = 0; u < NPC; u++)
+                if (loff[u] >= 0) buf2[loff[u]] = r[d][u];
+            fetch(c + d + D, r[d]);
+            __syncthreads();
+            acc += buf2[(tid * 5) % (384 * NB)];
+            __syncthreads();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (acc.x == 123.456f) out[0] = acc.y;
+    (void)lds_pad16;
+}
+
+__global__ void k_fill(float *x, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned h = (unsigned)i * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        x[i] = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    }
+}
+
 int main()
 {
     const size_t bytes = (size_t)10000 * 12864 * 8;      // the stage-2 scratch of 10 000 channels
@@ -104,5 +163,29 @@ int main()
     time("row stream, 1 chunk ahead", [&] { hipLaunchKernelGGL(k_rows<1>, dim3(10000), dim3(192), 0, 0, d, row16, 10000, o); });
     time("row stream, 2 chunks ahead", [&] { hipLaunchKernelGGL(k_rows<2>, dim3(10000), dim3(192), 0, 0, d, row16, 10000, o); });
     time("row stream, 4 chunks ahead", [&] { hipLaunchKernelGGL(k_rows<4>, dim3(10000), dim3(192), 0, 0, d, row16, 10000, o); });
+    auto rows2 = [&](const char *tag) {
+        char nm[96];
+        for (int lds : {16, 36}) {       // KB of LDS per workgroup: what decides the workgroups per CU (9 / 4)
+            snprintf(nm, 96, "k_tail_stream's loads NB=2 D=3, %d KB LDS%s", lds, tag);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rows2<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds * 1024);
+            time(nm, [&] { hipLaunchKernelGGL((k_rows2<2, 3>), dim3(10000), dim3(256), lds * 1024, 0, d, row16, 10000, o, 0); });
+            snprintf(nm, 96, "k_tail_stream's loads NB=1 D=4, %d KB LDS%s", lds, tag);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rows2<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds * 1024);
+            time(nm, [&] { hipLaunchKernelGGL((k_rows2<1, 4>), dim3(10000), dim3(256), lds * 1024, 0, d, row16, 10000, o, 0); });
+        }
+    };
+    rows2(" (constant data)");
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (float *)d, bytes / 4);
+    hipDeviceSynchronize();
+    rows2(" (random data)");
+    // the row pitch: 10 000 rows of 6 400 pieces read, rows `pitch` pieces apart (the buffer holds 10 000 x 6 432)
+    for (int pitch : {6432, 6400, 6408, 6416, 6424}) {
+        char nm[96];
+        snprintf(nm, 96, "k_tail_stream's loads NB=1 D=4, row pitch %d B (%s)", pitch * 16, pitch * 16 % 4096 == 0 ? "multiple of 4 KB" : "not a multiple of 4 KB");
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rows2<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024);
+        time(nm, [&] { hipLaunchKernelGGL((k_rows2<1, 4>), dim3(10000), dim3(256), 36 * 1024, 0, d, (size_t)pitch, 10000, o, 0); });
+    }
+    time("row stream, 1 chunk ahead (random data)", [&] { hipLaunchKernelGGL(k_rows<1>, dim3(10000), dim3(192), 0, 0, d, row16, 10000, o); });
+    time("one WG per 963 x16 B span (random data)", [&] { hipLaunchKernelGGL(k_span, dim3((unsigned)((n + 963 - 1) / 963)), dim3(256), 0, 0, d, n, o, 963); });
     return 0;
 }
