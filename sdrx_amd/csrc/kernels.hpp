@@ -1038,6 +1038,8 @@ struct TailArgs {
     const unsigned *next;
     int n_units;
     int unit_shift;         //   units per channel = 1 << unit_shift (k_tail_bgs claims half channels); *next counts units
+    const unsigned *skipped; //   [n_units] == epoch: the background kernel claimed (part of) the channel in this call and gave it back
+    unsigned epoch;         //   (it had waited too long for the channel's rows); this kernel runs it
     int half_split;         // 1: written by k_stage12m -- a body's four outputs of a segment lie as two pairs, one in each of the
                             // body's two half-body rows: [time-wave][2 body + h][segment][2] (kernels_mfma.hpp); y2b is 4
     float rcp_seg_len, rcp_ph_len, rcp_y2b;
@@ -1306,8 +1308,9 @@ __global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
     if (a.order) {                                         // what k_tail_bg left: units first .. n_units-1 of its list, from the
         // last one down (the rows written last are the ones still cached); a channel of which only a part was claimed runs whole
         const int first = (int)(min(*a.next, (unsigned)(a.n_units << a.unit_shift)) >> a.unit_shift);
-        if (a.n_units - 1 - chf < first) return;
-        ch = a.order[a.n_units - 1 - chf];
+        const int j = a.n_units - 1 - chf;
+        if (j < first && __hip_atomic_load(a.skipped + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) return;
+        ch = a.order[j];
     } else {
         ch = a.n_ch - 1 - chf;
         if (ch < a.ch_lo) return;
@@ -1332,7 +1335,40 @@ struct BgArgs {
     const int *order;        // [n_units] channel of unit i
     const int *set_of;       // [n_units] its set
     int n_units;
+    unsigned *skipped;       // [channels of `order`] = target: claimed in this call, but given back (see bg_claim)
+    int *disabled;           // != 0: a wait has run out once; the kernel claims nothing any more, in this call or a later one
 };
+
+#ifndef SDRX_BG_WAIT_TICKS
+#define SDRX_BG_WAIT_TICKS 5000000     // 50 ms of the 100 MHz clock (tests build the library with 0: every wait runs out)
+#endif
+// One claim of the background tail kernels, by thread 0 of the workgroup: the next unit of the list, once its set of slot groups is
+// complete (stop raised = the stage-1/2 kernel has ended: every set is).  The wait is bounded -- the stage-1/2 kernel may not be
+// running at all (both launches on one hardware queue, a GPU busy with somebody else's work): after 50 ms (5 M ticks of the
+// 100 MHz clock; the kernel itself takes 0.6 ms) the unit's channel goes back to k_tail_s (skipped[] = this call's target, which
+// k_tail_s compares with its epoch), the bank's background tail is switched off for good and the workgroup ends.  -1: nothing to do.
+__device__ __forceinline__ int bg_claim(const BgArgs &g, const int unit_shift)
+{
+    if (__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+        __hip_atomic_load(g.disabled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        return -1;
+    const int idx = (int)__hip_atomic_fetch_add(g.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (idx >= g.n_units) return -1;
+    const unsigned *d = g.done + g.set_of[idx >> unit_shift];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) {
+        if (__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)SDRX_BG_WAIT_TICKS) {
+            __hip_atomic_store(g.skipped + (idx >> unit_shift), g.target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.disabled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return -1;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 forgets what it held of the rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return idx;
+}
 
 template <int MA, int TA, int MB, int TB>
 __global__ __launch_bounds__(256) void k_tail_bg(const TailArgs a, const BgArgs g)
@@ -1344,27 +1380,7 @@ __global__ __launch_bounds__(256) void k_tail_bg(const TailArgs a, const BgArgs 
     // channels done beside k_stage12m, which loses 1 % more)
     __builtin_amdgcn_s_setprio(3);
     for (;;) {
-        if (tid == 0) {
-            int idx = -1;
-            if (!__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                idx = (int)__hip_atomic_fetch_add(g.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (idx >= g.n_units) idx = -1;
-            }
-            if (idx >= 0) {
-                // the unit's set complete?  (stop raised = the stage-1/2 kernel has ended: every set is.)  Bounded: ~2 s of
-                // 100 MHz ticks, then on regardless -- a hang is worse than a wrong block
-                const unsigned *d = g.done + g.set_of[idx];
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while ((int)(__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) {
-                    if (__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
-                    __builtin_amdgcn_s_sleep(32);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 forgets what it held of the rows
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            s_idx = idx;
-        }
+        if (tid == 0) s_idx = bg_claim(g, 0);
         __syncthreads();
         const int idx = s_idx;
         if (idx < 0) break;
@@ -1545,25 +1561,7 @@ __global__ __launch_bounds__(256, 6) void k_tail_bgs(const TailArgs a, const BgA
     const int tid = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);
     for (;;) {
-        if (tid == 0) {
-            int idx = -1;
-            if (!__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                idx = (int)__hip_atomic_fetch_add(g.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (idx >= g.n_units) idx = -1;
-            }
-            if (idx >= 0) {
-                const unsigned *d = g.done + g.set_of[idx >> 1];
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while ((int)(__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) {
-                    if (__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
-                    __builtin_amdgcn_s_sleep(32);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            s_idx = idx;
-        }
+        if (tid == 0) s_idx = bg_claim(g, 1);
         __syncthreads();
         const int idx = s_idx;
         if (idx < 0) break;

@@ -475,7 +475,8 @@ struct sdrxgpu_bank {
     bool bg_tail = false;
     hipStream_t stream_bg = nullptr;
     hipEvent_t ev_bg_go = nullptr, ev_bg_done = nullptr;
-    unsigned *d_bg_done = nullptr, *d_bg_next = nullptr;
+    unsigned *d_bg_done = nullptr, *d_bg_next = nullptr, *d_bg_skipped = nullptr;
+    int *d_bg_disabled = nullptr;
     int *d_bg_stop = nullptr, *d_bg_order = nullptr, *d_bg_set_of = nullptr;
     unsigned bg_target = 0;                           // items per set k_stage12m has reported when the current block is complete
     int bg_cus = 256;
@@ -554,6 +555,8 @@ static void free_bank(sdrxgpu_bank *b)
     (void)hipFree(b->d_slots);
     (void)hipFree(b->d_slots_m);
     (void)hipFree(b->d_bg_done);
+    (void)hipFree(b->d_bg_skipped);
+    (void)hipFree(b->d_bg_disabled);
     (void)hipFree(b->d_bg_next);
     (void)hipFree(b->d_bg_stop);
     (void)hipFree(b->d_bg_order);
@@ -1127,8 +1130,8 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 return fail(tune.bg_tail > 2 ? SDRXGPU_ERR_INVALID_ARG : SDRXGPU_ERR_UNSUPPORTED,
                             "bank_create: tuning.bg_tail %u (0..2; 2 needs the 10 MS/s chain's tail (5,21)(5,67), no pipelining, no generic tail)", tune.bg_tail);
             }
-            // (not automatic: measured 0.891 against 0.887 ms per 10 000-channel block -- k_tail_bg gets through a third of the
-            // channels while k_stage12m runs, which takes 9 % longer beside it)
+            // (not automatic: 0.877 against 0.895 ms per 10 000-channel block -- k_tail_bgs gets through 44 % of the tail while
+            // k_stage12m runs, which takes 12 % longer beside it; and the bench's roofline figure is that kernel's duration)
             b->bg_tail = can && tune.bg_tail == 2;
         }
         if (b->bg_tail) {
@@ -1144,6 +1147,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             }
             if ((rc2 = dev_alloc(b, (void **)&b->d_bg_done, n_sets * sizeof(unsigned))) ||
                 (rc2 = dev_alloc(b, (void **)&b->d_bg_next, 64)) || (rc2 = dev_alloc(b, (void **)&b->d_bg_stop, 64)) ||
+                (rc2 = dev_alloc(b, (void **)&b->d_bg_skipped, order.size() * sizeof(unsigned))) || (rc2 = dev_alloc(b, (void **)&b->d_bg_disabled, 64)) ||
                 (rc2 = dev_alloc(b, (void **)&b->d_bg_order, order.size() * sizeof(int))) ||
                 (rc2 = dev_alloc(b, (void **)&b->d_bg_set_of, set_of.size() * sizeof(int)))) {
                 free_bank(b);
@@ -1152,6 +1156,8 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             e = hipMemset(b->d_bg_done, 0, n_sets * sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(b->d_bg_next, 0, 64);
             if (e == hipSuccess) e = hipMemset(b->d_bg_stop, 0, 64);
+            if (e == hipSuccess) e = hipMemset(b->d_bg_skipped, 0, order.size() * sizeof(unsigned));     // (a call's target is never 0)
+            if (e == hipSuccess) e = hipMemset(b->d_bg_disabled, 0, 64);
             if (e == hipSuccess) e = hipMemcpy(b->d_bg_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(b->d_bg_set_of, set_of.data(), set_of.size() * sizeof(int), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream_bg, hipStreamNonBlocking);
@@ -1427,6 +1433,10 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
     info->matrix_pipe = b->mfma ? 1u : 0u;
     info->m_slots = b->mfma ? (uint32_t)b->n_slots_m : 0u;
     info->bg_tail = b->bg_tail ? 1u : 0u;
+    if (b->bg_tail) {                                      // switched itself off since? (bg_claim: a wait ran out)
+        int off = 0;
+        if (hipMemcpy(&off, b->d_bg_disabled, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && off) info->bg_tail = 2u;
+    }
     return SDRXGPU_OK;
 }
 
@@ -1879,6 +1889,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         t.next = nullptr;
         t.n_units = 0;
         t.unit_shift = 0;
+        t.skipped = nullptr;
+        t.epoch = 0;
         // k_tail_bgs (half channels, streamed) where the scratch has k_stage12m's whole-segment layout, else k_tail_bg (channels, tile by tile)
         const bool stream_layout = t.half_split && t.P == 1 && t.spw == 16 && t.seg_len == 48 && t.hist % 2 == 0 && t.hist >= 2 && t.hist <= 768;
         const bool bg_stream = overlap && stream_layout && bgs_lds_bytes() + k12m_lds_bytes(b->mGS, b->mGT) * 2 <= 160 * 1024;
@@ -1897,6 +1909,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             g.stop = b->d_bg_stop;
             g.order = b->d_bg_order;
             g.set_of = b->d_bg_set_of;
+            g.skipped = b->d_bg_skipped;
+            g.disabled = b->d_bg_disabled;
             g.n_units = bg_stream ? 2 * (int)b->n_ch : (int)b->n_ch;
             // one workgroup per CU, launched BEFORE the stage-1/2 kernel: it has its place when that kernel's workgroups arrive
             if (bg_stream)
@@ -1922,6 +1936,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             t.next = b->d_bg_next;
             t.n_units = (int)b->n_ch;
             t.unit_shift = bg_stream ? 1 : 0;
+            t.skipped = b->d_bg_skipped;
+            t.epoch = b->bg_target;
         }
         ProfScope ps(b, SDRXGPU_K_TAIL);
         const dim3 grid(((n_part + 7) / 8 * 8) * t.n_tiles);
