@@ -54,14 +54,17 @@ struct Stage12mTaps {
     float h2[10];       // h2[0 .. 9]; h2[18 - e] = h2[e] (the reference reads that half only, msd.hpp:309-331): 10 scalar register pairs, not 19
 };
 
-// TRIM: skip the first six phases of a lane's warm-up body (nobody's input): -1.5 % on the launch, but the second path through the
-// half-body costs registers -- 256 VGPRs and a few spills instead of 209; the launch beside k_tail_bg needs the 209.
-template <int GS, int GT, bool TRIM>
+// LEAN = false (the ordinary launch): the first six phases of a lane's warm-up body (nobody's input) are skipped (-1.5 %), and a wave's
+// memory instructions -- LDS-DMA for the next half-body, stores of the previous one's outputs -- go out a piece per phase instead
+// of in a burst behind the barrier (-5 %): 256 VGPRs and a dozen spills.  LEAN = true: neither; 210 VGPRs, what the launch beside
+// k_tail_bg / k_tail_bgs may have (two of these waves and one of theirs per SIMD).
+template <int GS, int GT, bool LEAN>
 __global__ __launch_bounds__(64 * GS * GT, 2)
 void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
                 const Stage12Args a, const PairArgs pa, const Stage12mTaps taps)
 {
     using G = TileGeomM<GS, GT>;
+    constexpr bool TRIM = !LEAN, SPREAD = !LEAN;
     constexpr int SB = 100, Y2B = 4, SPW = 16;
     constexpr int RB = G::row_bytes;
     extern __shared__ __attribute__((aligned(16))) char lds_m[];
@@ -140,16 +143,16 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     if (tph < 0) tph += a.N;
     const char *xsrc0 = reinterpret_cast<const char *>(x_in + a.x_base - G::HALO);
     const char *tsrc0 = reinterpret_cast<const char *>(tables);
-    auto issue_half = [&](int hb, int bi, int tphh) {
+    static_assert(G::pairs == G::pairs_per_wave * G::waves, "every wave moves the same number of row pairs");
+    auto issue_one = [&](int i, int hb, int bi, int tphh) {
         char *buf = lds_m + bi * G::buf_bytes;
+        const int k = wave + i * G::waves;
+        const char *base = dma_is_t[i] ? tsrc0 + (size_t)tphh * 8 : xsrc0 + (size_t)hb * G::HB * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(base + dma_off[i]), (lds_void *)(uint32_t)(uintptr_t)(buf + 2 * k * RB), 16, 0, 0);
+    };
+    auto issue_half = [&](int hb, int bi, int tphh) {
 #pragma unroll
-        for (int i = 0; i < G::pairs_per_wave; i++) {
-            const int k = wave + i * G::waves;
-            if (k < G::pairs) {
-                const char *base = dma_is_t[i] ? tsrc0 + (size_t)tphh * 8 : xsrc0 + (size_t)hb * G::HB * 8;
-                __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(base + dma_off[i]), (lds_void *)(uint32_t)(uintptr_t)(buf + 2 * k * RB), 16, 0, 0);
-            }
-        }
+        for (int i = 0; i < G::pairs_per_wave; i++) issue_one(i, hb, bi, tphh);
     };
 
     // ---- operand addresses (byte offsets inside a buffer) ----
@@ -228,23 +231,24 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     // the 16 lanes of a channel write 256 contiguous bytes per store and no 32-byte sector is written in two goes (with whole
     // bodies of four outputs per segment the two halves of every sector came ten phases apart: 2.0 GB of HBM writes per
     // launch for 1.07 GB of outputs).  The tail kernels are told so (y2b = 2, twice the bodies).
-    v2f stage[2][8];
+    v4f stage[8];                                           // per channel: (re, im) of the half-body's first output, of its second
     const uint32_t ylane = (uint32_t)a.y2_hist + ((uint32_t)wt * (2 * a.nb) * SPW + lo) * 2;
-    auto store_staged = [&](int body, int h) {
+    auto store_staged_part = [&](int body, int h, int i0, int i1) {     // channels i0 .. i1 - 1 of the lane's eight
         if (body < 0 || !seg_live) return;
         const uint32_t at = ylane + (uint32_t)(2 * body + h) * SPW * 2;
         if (a.done) {       // beside k_tail_bg: write-through, so that a counter behind vmcnt(0) + barrier publishes the rows (MI355X_MICROARCH.md, valid forms)
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const v4f v = v4f{stage[0][i].x, stage[0][i].y, stage[1][i].x, stage[1][i].y};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(y2_out + (size_t)(yrow[i] + at)), "v"(v) : "memory");
-            }
+            for (int i = i0; i < i1; i++)
+                asm volatile("global_store_dwordx4 %0, %1, %2 sc1" : : "v"((yrow[i] + at) * 8u), "v"(stage[i]), "s"(y2_out) : "memory");
             return;
         }
+        // (scalar base + 32-bit byte offset per lane: one address register per store -- these stores sit between the phases now,
+        // where the register file is full; the host keeps the scratch below 4 GB)
 #pragma unroll
-        for (int i = 0; i < 8; i++)
-            *reinterpret_cast<v4f *>(y2_out + (size_t)(yrow[i] + at)) = v4f{stage[0][i].x, stage[0][i].y, stage[1][i].x, stage[1][i].y};
+        for (int i = i0; i < i1; i++)
+            *reinterpret_cast<v4f *>(reinterpret_cast<char *>(y2_out) + (size_t)((yrow[i] + at) * 8u)) = stage[i];
     };
+    auto store_staged = [&](int body, int h) { store_staged_part(body, h, 0, 8); };
     // combinations + stage 2 for stage-1 output P20 (0..19) of a body
     auto post = [&](auto p20_tag, const Acc &c) {
         constexpr int P20 = decltype(p20_tag)::value;
@@ -281,7 +285,10 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         }
         if constexpr (u == 4) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) stage[s & 1][i] = acc2[s & 3][i];
+            for (int i = 0; i < 8; i++) {
+                if constexpr ((s & 1) == 0) { stage[i].x = acc2[s & 3][i].x; stage[i].y = acc2[s & 3][i].y; }
+                else { stage[i].z = acc2[s & 3][i].x; stage[i].w = acc2[s & 3][i].y; }
+            }
         }
     };
 
@@ -296,12 +303,26 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
             const int hb = 2 * b + half;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            const int tph_prev = tph;
             tph += G::HB;
             if (tph >= a.N) tph -= a.N;
-            if (hb + 1 < 2 * n_bodies) issue_half(hb + 1, (half + 1) & 1, tph);
-            // the outputs the previous half-body completed
-            if (half == 0) store_staged(body - 1, 1);
-            else store_staged(body, 0);
+            // What a wave has to move besides goes out a piece per phase: its share of the next half-body's rows (LDS-DMA i in phase i;
+            // the last one two phases before the barrier that waits for it) and the two outputs per channel the previous half-body
+            // completed (8 stores: channels 2 ph, 2 ph + 1 in phases 0 .. 3; phase 4 completes the next output into the staging
+            // registers).  As one burst behind the barrier these 16 memory instructions cost the wave 2 400 of its 14 200 cycles per
+            // half-body (s_memtime stamps: 185 cycles per DMA, 115 per store, into a queue the other waves' bursts have filled),
+            // cycles in which it feeds nothing to the matrix pipe, and the one other wave of the SIMD cannot keep that pipe busy
+            // alone.  No branch may stand in a phase for this (with one the kernel needs 77 registers more than there are):
+            // (behind the last half-body: the same rows once more, into the buffer nobody reads any more -- no branch in the phases)
+            const int nhb = min(hb + 1, 2 * n_bodies - 1), nbi = (half + 1) & 1;
+            const int ntph = hb + 1 < 2 * n_bodies ? tph : tph_prev;
+            if constexpr (!SPREAD) {
+                if (hb + 1 < 2 * n_bodies) issue_half(hb + 1, nbi, tph);
+                store_staged(half == 0 ? body - 1 : body, half == 0 ? 1 : 0);
+            } else {
+                if (!seg_live) issue_half(nhb, nbi, ntph);
+            }
+            const int sbody = half == 0 ? body - 1 : body, sh = half == 0 ? 1 : 0;
             // the ten phases: phase ph goes to the matrix pipe, the operands of phase ph+1 are fetched into the registers
             // the MFMAs have just read, then phase ph is finished on the vector pipe (the fetch covers the MFMA latency)
             auto window = [&](auto ph_tag) {
@@ -313,11 +334,13 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
                 mfma_phase(ops, acc);
                 if constexpr (ph + 1 < 10) load_ops(P20 / 10, ph + 1, ops);
                 __builtin_amdgcn_s_setprio(0);
+                if constexpr (SPREAD && ph < G::pairs_per_wave) issue_one(ph, nhb, nbi, ntph);
+                if constexpr (SPREAD && ph < 4) store_staged_part(sbody, sh, 2 * ph, 2 * ph + 2);
                 post(std::integral_constant<int, P20>{}, acc);
                 __builtin_amdgcn_sched_barrier(0);
             };
             // from6: the warm-up body's first half.  Stage 2's first real output has the stage-1 outputs from phase 6 of the
-            // warm-up body on as its window: phases 0..5 of that body are nobody's input and are skipped.
+            // warm-up body on as its window: phases 0..5 of that body are nobody's input and are skipped (nothing to store yet).
             auto run_half = [&](auto h_tag, const bool from6) {
                 constexpr int H = decltype(h_tag)::value;
                 if (!from6) {
@@ -329,6 +352,10 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
                     window(std::integral_constant<int, H * 10 + 4>{});
                     window(std::integral_constant<int, H * 10 + 5>{});
                 } else {
+                    if constexpr (SPREAD) {
+#pragma unroll
+                        for (int i = 0; i < 6 && i < G::pairs_per_wave; i++) issue_one(i, nhb, nbi, ntph);
+                    }
                     load_ops(H, 6, ops);
                 }
                 window(std::integral_constant<int, H * 10 + 6>{});
@@ -336,14 +363,19 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
                 window(std::integral_constant<int, H * 10 + 8>{});
                 window(std::integral_constant<int, H * 10 + 9>{});
             };
-            // (a wave whose segment group lies past the end of the data only keeps the workgroup's barriers and its share of the DMAs)
             if (seg_live) {
                 if (half == 0) run_half(std::integral_constant<int, 0>{}, TRIM && b == 0);
                 else run_half(std::integral_constant<int, 1>{}, false);
             }
+            // (a wave whose segment group lies past the end of the data only keeps the workgroup's barriers and its share of the DMAs)
         }
     }
     store_staged(a.nb - 1, 1);                                  // the last half-body's outputs
+    // (the last half-body's extra DMAs went to buffer 0, where the next item's first rows go: they have to be in, everybody's)
+    if (SPREAD && item + (int)gridDim.x < n_items) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (a.done) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's stores have left it ...
         __syncthreads();

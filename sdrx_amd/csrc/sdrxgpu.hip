@@ -305,25 +305,25 @@ static size_t bgs_lds_bytes() { return (size_t)(24 + 768 * SDRX_BGS_NB + 5 * 255
 static bool k12m_geometry_compiled(int GS, int GT) { return (GS == 2 && GT == 2) || (GS == 4 && GT == 2) || (GS == 2 && GT == 4); }
 static size_t k12m_lds_bytes(int GS, int GT) { return 2 * (size_t)(16 * GS + 16 * GT) * 528; }
 
-template <int GS, int GT, bool TRIM>
+template <int GS, int GT, bool LEAN>
 static hipError_t launch_k12m_one(const K12mLaunch &M, const Stage12mTaps &taps, hipStream_t s)
 {
     using TG = TileGeomM<GS, GT>;
     static_assert(2 * TG::buf_bytes <= 160 * 1024, "two tile buffers must fit the LDS");
-    hipLaunchKernelGGL((k_stage12m<GS, GT, TRIM>), dim3(M.L.grid), dim3(64 * GS * GT), 2 * TG::buf_bytes, s,
+    hipLaunchKernelGGL((k_stage12m<GS, GT, LEAN>), dim3(M.L.grid), dim3(64 * GS * GT), 2 * TG::buf_bytes, s,
                        M.L.x, M.L.tables, M.L.y2, M.L.args, M.pa, taps);
     return hipGetLastError();
 }
 
-// `lean`: the 209-VGPR build (whole warm-up body) that leaves a SIMD room for a wave of k_tail_bg beside two of its own
+// `lean`: the 210-VGPR build (whole warm-up body, memory instructions in a burst) that leaves a SIMD room for a wave of k_tail_bg beside two of its own
 static hipError_t launch_k12m(const K12mLaunch &M, bool lean, hipStream_t s)
 {
     Stage12mTaps taps{};
     for (int i = 0; i < 17; i++) taps.h1[i] = M.L.h1[i < 9 ? i : 16 - i];     // (the reference reads h[0 .. half] only, msd.hpp:309-331)
     for (int i = 0; i < 10; i++) taps.h2[i] = M.L.h2[i];
-    if (M.GS == 2 && M.GT == 2) return lean ? launch_k12m_one<2, 2, false>(M, taps, s) : launch_k12m_one<2, 2, true>(M, taps, s);
-    if (M.GS == 4 && M.GT == 2) return lean ? launch_k12m_one<4, 2, false>(M, taps, s) : launch_k12m_one<4, 2, true>(M, taps, s);
-    if (M.GS == 2 && M.GT == 4) return lean ? launch_k12m_one<2, 4, false>(M, taps, s) : launch_k12m_one<2, 4, true>(M, taps, s);
+    if (M.GS == 2 && M.GT == 2) return lean ? launch_k12m_one<2, 2, true>(M, taps, s) : launch_k12m_one<2, 2, false>(M, taps, s);
+    if (M.GS == 4 && M.GT == 2) return lean ? launch_k12m_one<4, 2, true>(M, taps, s) : launch_k12m_one<4, 2, false>(M, taps, s);
+    if (M.GS == 2 && M.GT == 4) return lean ? launch_k12m_one<2, 4, true>(M, taps, s) : launch_k12m_one<2, 4, false>(M, taps, s);
     return hipErrorInvalidValue;
 }
 
@@ -1617,8 +1617,8 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
         M.pa.group_conj = nullptr;
         M.pa.n_slots = whole ? b->n_slots_m : b->n_slots_mp;
         M.pa.lds_bytes = (int)k12m_lds_bytes(b->mGS, b->mGT);
-        if ((uint64_t)(b->n_ch + 1) * (uint64_t)b->y2_stride >= (1ull << 32))
-            return fail(SDRXGPU_ERR_HIP, "internal: stage-2 scratch of %u x %d entries exceeds k_stage12m's 32-bit row offsets", b->n_ch, b->y2_stride);
+        if ((uint64_t)(b->n_ch + 1) * (uint64_t)b->y2_stride * sizeof(float2) >= (1ull << 32))
+            return fail(SDRXGPU_ERR_HIP, "internal: stage-2 scratch of %u x %d entries exceeds k_stage12m's 32-bit byte offsets", b->n_ch, b->y2_stride);
         HIPCHK(launch_k12m(M, M.L.args.done != nullptr, st));        // (beside k_tail_bg: the build that leaves it room)
         return SDRXGPU_OK;
     }
