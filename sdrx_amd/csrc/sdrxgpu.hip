@@ -717,9 +717,10 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     b->WU = (halo + b->SB - 1) / b->SB;
     b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
     // Mixer + stage 1 on the f32 matrix pipe (k_stage12m): the 10 MS/s chain with translator tables, banks of
-    // 8 192 channels or more unless tuning says otherwise (measured against the vector kernels' automatic path, ms per block:
-    // 4 096 channels 0.50 / 0.45, 6 144: 0.66 / 0.64, 7 168: 0.76 / 0.72, 8 192: 0.79 / 0.83, 10 000: 0.94 / 1.02, 16 384:
-    // 1.54 / 1.61, 25 000: 2.33 / 2.48).  Its input rows start T1 - M1 samples in front of a body.
+    // 3 584 channels or more unless tuning says otherwise (measured against the vector kernels' automatic path, ms per block:
+    // 3 072 channels 0.408 / 0.359, 3 328: 0.417 / 0.374, 3 584: 0.380 / 0.397, 3 840: 0.389 / 0.416, 4 096: 0.427 / 0.464,
+    // 5 120: 0.548 / 0.571, 6 144: 0.594 / 0.648, 7 168: 0.691 / 0.727, 8 192: 0.725 / 0.831, 10 000: 0.863 / 0.990; up to
+    // 3 640 channels its workgroups all find a place at once).  Its input rows start T1 - M1 samples in front of a body.
     const sdrxgpu_tuning tune0 = cfg->tuning ? *cfg->tuning : sdrxgpu_tuning{};
     {
         const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && N > 0 && (N % 2) == 0;
@@ -739,7 +740,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             free_bank(b);
             return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe = 2 goes with neither fused_tail = 2, pair_lanes = 2 nor k12_waves / k12_cpw");
         }
-        b->mfma = can && (tune0.matrix_pipe == 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 8192));
+        b->mfma = can && (tune0.matrix_pipe == 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 3584));
         if (b->mfma) {
             b->mGS = tune0.m_slot_groups ? (int)tune0.m_slot_groups : 2;
             b->mGT = tune0.m_seg_groups ? (int)tune0.m_seg_groups : 2;

@@ -125,9 +125,10 @@ def test_a_channels_bits_do_not_depend_on_who_else_is_in_the_bank():
     assert np.array_equal(alone[1].view(np.uint32), swapped[0].view(np.uint32))
 
 
-def test_large_bank_by_default_host_parts_and_oracle(oracle):
+@pytest.mark.parametrize("n_ch", [3584, 10000])
+def test_large_bank_by_default_host_parts_and_oracle(oracle, n_ch):
+    """The default path from 3 584 channels (the measured crossover) on; 10 000 = the bench workload, four host parts."""
     ch = chains.chain("10")
-    n_ch = 10000                                           # the bench workload: the default path from 8 192 channels; four host parts
     offs = chains.offsets_cycled(n_ch, ch.N)
     tabs = sb.translators_for(ch, offs)
     L = ch.block_len
@@ -144,10 +145,12 @@ def test_large_bank_by_default_host_parts_and_oracle(oracle):
         assert np.array_equal(iq[c].view(np.uint32), iq[c + ch.N].view(np.uint32))
     worst_iq = worst_au = 0.0
     for c in (0, 1, 599, 600, 601, 1199, 1200, 2559, 2560, 4999, 7777, 9999):
+        if c >= n_ch:
+            continue
         riq, rau = _oracle(oracle, ch, [tabs[c]], blocks)
         worst_iq = max(worst_iq, rel_err_rows(iq[c:c + 1], riq))
         worst_au = max(worst_au, rel_err_rows(au[c:c + 1], rau))
-    margin("matrix_pipe_10000ch_vs_oracle", iq=worst_iq, audio=worst_au)
+    margin("matrix_pipe_%dch_vs_oracle" % n_ch, iq=worst_iq, audio=worst_au)
     assert worst_iq <= RTOL and worst_au <= RTOL
 
 
