@@ -185,6 +185,18 @@ int main()
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rows2<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024);
         time(nm, [&] { hipLaunchKernelGGL((k_rows2<1, 4>), dim3(10000), dim3(256), 36 * 1024, 0, d, (size_t)pitch, 10000, o, 0); });
     }
+    // sustained: the same span reader 2 000 times back to back (0.3 s of nothing but reads), mean of the last 500
+    {
+        auto launch = [&] { hipLaunchKernelGGL(k_span, dim3((unsigned)((n + 963 - 1) / 963)), dim3(256), 0, 0, d, n, o, 963); };
+        for (int i = 0; i < 1500; i++) launch();
+        hipEventRecord(e0);
+        for (int i = 0; i < 500; i++) launch();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("%-44s %.3f ms  %.2f TB/s\n", "one WG per 963 x16 B span, sustained (mean of launches 1 501-2 000)", ms / 500, bytes / (ms / 500) * 1e-9);
+    }
     time("row stream, 1 chunk ahead (random data)", [&] { hipLaunchKernelGGL(k_rows<1>, dim3(10000), dim3(192), 0, 0, d, row16, 10000, o); });
     time("one WG per 963 x16 B span (random data)", [&] { hipLaunchKernelGGL(k_span, dim3((unsigned)((n + 963 - 1) / 963)), dim3(256), 0, 0, d, n, o, 963); });
     return 0;
