@@ -107,8 +107,8 @@ typedef struct {
                                 from the others', by rounding only): 0 = auto, 1 = never, 2 = require            */
     uint32_t bg_tail;        /* banks on the matrix pipe: the tail stages run BESIDE the stage-1/2 kernel of the same block (one
                                 persistent low-footprint workgroup per CU takes the channels whose slot groups are complete;
-                                device and pinned entries; same outputs bit for bit): 0 = auto (off: 2 % of a 10 000-channel
-                                block, paid for with a stage-1/2 kernel that runs 12 % longer beside it),
+                                device and pinned entries; same outputs bit for bit): 0 = auto (off: 1 to 3.4 % of a 10 000-channel
+                                block depending on the box, paid for with a stage-1/2 kernel that runs 10 % longer beside it),
                                 1 = never, 2 = require.  Needs the two kernels to run at the same time: launches that the
                                 runtime puts on one hardware queue do not, the kernel then gives its channels back after
                                 50 ms, once, and switches itself off (bank_info.bg_tail == 2) */

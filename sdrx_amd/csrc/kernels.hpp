@@ -1552,9 +1552,9 @@ __device__ __forceinline__ void tail_stream_unit(const TailArgs &a, const int ch
     }
 }
 
-template <int MA, int TA, int MB, int TB, int NB>
-// (launch bounds: 6 waves per SIMD as the register budget = 80 VGPRs, what two waves of k_stage12m leave on a SIMD)
-__global__ __launch_bounds__(256, 6) void k_tail_bgs(const TailArgs a, const BgArgs g)
+template <int MA, int TA, int MB, int TB, int NB, int DEPTH>
+// (launch bounds: 5 waves per SIMD as the register budget = 102 VGPRs; two waves of k_stage12m's lean build, 208 each, leave 96)
+__global__ __launch_bounds__(256, 5) void k_tail_bgs(const TailArgs a, const BgArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     __shared__ int s_idx;
@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(256, 6) void k_tail_bgs(const TailArgs a, const BgA
         __syncthreads();
         const int idx = s_idx;
         if (idx < 0) break;
-        tail_stream_unit<MA, TA, MB, TB, NB, 256, 1>(a, g.order[idx >> 1], idx & 1, smem);
+        tail_stream_unit<MA, TA, MB, TB, NB, 256, DEPTH>(a, g.order[idx >> 1], idx & 1, smem);
         __syncthreads();
     }
 }

@@ -54,17 +54,18 @@ struct Stage12mTaps {
     float h2[10];       // h2[0 .. 9]; h2[18 - e] = h2[e] (the reference reads that half only, msd.hpp:309-331): 10 scalar register pairs, not 19
 };
 
-// LEAN = false (the ordinary launch): the first six phases of a lane's warm-up body (nobody's input) are skipped (-1.5 %), and a wave's
-// memory instructions -- LDS-DMA for the next half-body, stores of the previous one's outputs -- go out a piece per phase instead
-// of in a burst behind the barrier (-5 %): 256 VGPRs and a dozen spills.  LEAN = true: neither; 210 VGPRs, what the launch beside
-// k_tail_bg / k_tail_bgs may have (two of these waves and one of theirs per SIMD).
+// A wave's memory instructions -- LDS-DMA for the next half-body, stores of the previous one's outputs -- go out a piece per phase
+// instead of in a burst behind the barrier (-5 % on the launch).  LEAN = false (the ordinary launch): also, the first six phases of
+// a lane's warm-up body (nobody's input) are skipped (-1.5 %): a second path through the half-body, 256 VGPRs and a few spills.
+// LEAN = true: not that; 206 VGPRs, what the launch beside k_tail_bg / k_tail_bgs may have (two of these waves and one of theirs
+// per SIMD: 2 x 216 + 80).
 template <int GS, int GT, bool LEAN>
 __global__ __launch_bounds__(64 * GS * GT, 2)
 void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
                 const Stage12Args a, const PairArgs pa, const Stage12mTaps taps)
 {
     using G = TileGeomM<GS, GT>;
-    constexpr bool TRIM = !LEAN, SPREAD = !LEAN;
+    constexpr bool TRIM = !LEAN;
     constexpr int SB = 100, Y2B = 4, SPW = 16;
     constexpr int RB = G::row_bytes;
     extern __shared__ __attribute__((aligned(16))) char lds_m[];
@@ -121,23 +122,38 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     const int rsel = lane < G::pieces_a ? 0 : 1;
     // (rows of segments past the last segment group that holds data re-read its last segment: inside the ring)
     const int seg_max = ((a.n_y2_new + Y2B - 1) / Y2B + SPW * bps - 1) / (SPW * bps) * SPW - 1;
-    uint32_t dma_off[G::pairs_per_wave];                    // per-lane byte offset from the pair's wave-uniform base
+    // per pair and lane: the byte offset from the pair's wave-uniform base.  The ordinary build keeps it in a register per pair;
+    // the lean build keeps the two rows' offsets of a pair as scalars and lets the lane add its piece at the DMA (8 registers less
+    // -- what brings it under the 216 it may have --, 1.4 % more time)
+    uint32_t dma_off[LEAN ? 1 : G::pairs_per_wave];
+    uint32_t dma_row[LEAN ? G::pairs_per_wave : 1][2];
     int dma_is_t[G::pairs_per_wave];
+    const uint32_t piece16 = (uint32_t)piece * 16u;
 #pragma unroll
     for (int i = 0; i < G::pairs_per_wave; i++) {
         const int k = wave + i * G::waves;
-        const int row = 2 * k + rsel;
         dma_is_t[i] = (2 * k >= G::x_rows);
-        if (2 * k < G::x_rows) {
-            const int seg = min((g_first + row / 16) * SPW + (row & 15), seg_max);
-            dma_off[i] = (uint32_t)(((long long)seg * bps + a.nb * p) * SB * 8 + piece * 16);
-        } else {
+        auto row_off = [&](int row) -> uint32_t {
+            if (2 * k < G::x_rows) {
+                const int seg = min((g_first + row / 16) * SPW + (row & 15), seg_max);
+                return (uint32_t)(((long long)seg * bps + a.nb * p) * SB * 8);
+            }
             const int s = cgm * GS * 16 + (row - G::x_rows);
             int c = s < pa.n_slots ? pa.slots[s].x : -1;
             if (c < 0) c = 0;                               // an empty slot works on channel 0's table and stores nothing
-            dma_off[i] = (uint32_t)((size_t)c * a.tbl_stride * 8 + piece * 16);
+            return (uint32_t)((size_t)c * a.tbl_stride * 8);
+        };
+        if constexpr (LEAN) {
+            dma_row[i][0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_off(2 * k));
+            dma_row[i][1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_off(2 * k + 1));
+        } else {
+            dma_off[i] = row_off(2 * k + rsel) + piece16;
         }
     }
+    auto lane_off = [&](int i) -> uint32_t {
+        if constexpr (LEAN) return (rsel ? dma_row[i][1] : dma_row[i][0]) + piece16;
+        else return dma_off[i];
+    };
     int tph = a.tphase0 + p * a.nb * SB - G::HALO;          // translator index of the first entry of half-body 0's rows
     tph %= a.N;
     if (tph < 0) tph += a.N;
@@ -148,7 +164,7 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         char *buf = lds_m + bi * G::buf_bytes;
         const int k = wave + i * G::waves;
         const char *base = dma_is_t[i] ? tsrc0 + (size_t)tphh * 8 : xsrc0 + (size_t)hb * G::HB * 8;
-        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(base + dma_off[i]), (lds_void *)(uint32_t)(uintptr_t)(buf + 2 * k * RB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(base + lane_off(i)), (lds_void *)(uint32_t)(uintptr_t)(buf + 2 * k * RB), 16, 0, 0);
     };
     auto issue_half = [&](int hb, int bi, int tphh) {
 #pragma unroll
@@ -316,12 +332,7 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
             // (behind the last half-body: the same rows once more, into the buffer nobody reads any more -- no branch in the phases)
             const int nhb = min(hb + 1, 2 * n_bodies - 1), nbi = (half + 1) & 1;
             const int ntph = hb + 1 < 2 * n_bodies ? tph : tph_prev;
-            if constexpr (!SPREAD) {
-                if (hb + 1 < 2 * n_bodies) issue_half(hb + 1, nbi, tph);
-                store_staged(half == 0 ? body - 1 : body, half == 0 ? 1 : 0);
-            } else {
-                if (!seg_live) issue_half(nhb, nbi, ntph);
-            }
+            if (!seg_live) issue_half(nhb, nbi, ntph);       // (a wave without data: its share of the DMAs, in one go)
             const int sbody = half == 0 ? body - 1 : body, sh = half == 0 ? 1 : 0;
             // the ten phases: phase ph goes to the matrix pipe, the operands of phase ph+1 are fetched into the registers
             // the MFMAs have just read, then phase ph is finished on the vector pipe (the fetch covers the MFMA latency)
@@ -334,8 +345,8 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
                 mfma_phase(ops, acc);
                 if constexpr (ph + 1 < 10) load_ops(P20 / 10, ph + 1, ops);
                 __builtin_amdgcn_s_setprio(0);
-                if constexpr (SPREAD && ph < G::pairs_per_wave) issue_one(ph, nhb, nbi, ntph);
-                if constexpr (SPREAD && ph < 4) store_staged_part(sbody, sh, 2 * ph, 2 * ph + 2);
+                if constexpr (ph < G::pairs_per_wave) issue_one(ph, nhb, nbi, ntph);
+                if constexpr (ph < 4) store_staged_part(sbody, sh, 2 * ph, 2 * ph + 2);
                 post(std::integral_constant<int, P20>{}, acc);
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -352,10 +363,8 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
                     window(std::integral_constant<int, H * 10 + 4>{});
                     window(std::integral_constant<int, H * 10 + 5>{});
                 } else {
-                    if constexpr (SPREAD) {
 #pragma unroll
-                        for (int i = 0; i < 6 && i < G::pairs_per_wave; i++) issue_one(i, nhb, nbi, ntph);
-                    }
+                    for (int i = 0; i < 6 && i < G::pairs_per_wave; i++) issue_one(i, nhb, nbi, ntph);
                     load_ops(H, 6, ops);
                 }
                 window(std::integral_constant<int, H * 10 + 6>{});
@@ -372,7 +381,7 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     }
     store_staged(a.nb - 1, 1);                                  // the last half-body's outputs
     // (the last half-body's extra DMAs went to buffer 0, where the next item's first rows go: they have to be in, everybody's)
-    if (SPREAD && item + (int)gridDim.x < n_items) {
+    if (item + (int)gridDim.x < n_items) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }

@@ -297,6 +297,9 @@ struct K12mLaunch {
     int GS, GT;
 };
 
+#ifndef SDRX_BGS_DEPTH
+#define SDRX_BGS_DEPTH 1    // chunks of k_tail_bgs in flight per workgroup (12 registers per thread each; 2 measured the same, 3 worse)
+#endif
 #ifndef SDRX_BGS_NB
 #define SDRX_BGS_NB 2       // time-wave blocks per chunk of k_tail_bgs (its LDS: 24 + 768 NB + 1 342 entries)
 #endif
@@ -315,7 +318,7 @@ static hipError_t launch_k12m_one(const K12mLaunch &M, const Stage12mTaps &taps,
     return hipGetLastError();
 }
 
-// `lean`: the 210-VGPR build (whole warm-up body, memory instructions in a burst) that leaves a SIMD room for a wave of k_tail_bg beside two of its own
+// `lean`: the 206-VGPR build (whole warm-up body) that leaves a SIMD room for a wave of k_tail_bg beside two of its own
 static hipError_t launch_k12m(const K12mLaunch &M, bool lean, hipStream_t s)
 {
     Stage12mTaps taps{};
@@ -1131,8 +1134,9 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 return fail(tune.bg_tail > 2 ? SDRXGPU_ERR_INVALID_ARG : SDRXGPU_ERR_UNSUPPORTED,
                             "bank_create: tuning.bg_tail %u (0..2; 2 needs the 10 MS/s chain's tail (5,21)(5,67), no pipelining, no generic tail)", tune.bg_tail);
             }
-            // (not automatic: 0.877 against 0.895 ms per 10 000-channel block -- k_tail_bgs gets through 44 % of the tail while
-            // k_stage12m runs, which takes 12 % longer beside it; and the bench's roofline figure is that kernel's duration)
+            // (not automatic: 0.842-0.863 against 0.867-0.872 ms per 10 000-channel block, 1 to 3.4 % depending on the box --
+            // k_tail_bgs gets through 40 % of the tail while k_stage12m runs, which takes 10 % longer beside it; and the bench's
+            // roofline figure is that kernel's duration)
             b->bg_tail = can && tune.bg_tail == 2;
         }
         if (b->bg_tail) {
@@ -1165,7 +1169,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_bg_go, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_bg_done, hipEventDisableTiming);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_bg<5, 21, 5, 67>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->tail_lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_bgs<5, 21, 5, 67, SDRX_BGS_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bgs_lds_bytes());
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_bgs<5, 21, 5, 67, SDRX_BGS_NB, SDRX_BGS_DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bgs_lds_bytes());
             if (e != hipSuccess) {
                 free_bank(b);
                 return fail(SDRXGPU_ERR_HIP, "k_tail_bg set-up failed: %s", hipGetErrorString(e));
@@ -1915,7 +1919,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             g.n_units = bg_stream ? 2 * (int)b->n_ch : (int)b->n_ch;
             // one workgroup per CU, launched BEFORE the stage-1/2 kernel: it has its place when that kernel's workgroups arrive
             if (bg_stream)
-                hipLaunchKernelGGL((k_tail_bgs<5, 21, 5, 67, SDRX_BGS_NB>), dim3(b->bg_cus), dim3(256), bgs_lds_bytes(), b->stream_bg, t, g);
+                hipLaunchKernelGGL((k_tail_bgs<5, 21, 5, 67, SDRX_BGS_NB, SDRX_BGS_DEPTH>), dim3(b->bg_cus), dim3(256), bgs_lds_bytes(), b->stream_bg, t, g);
             else
                 hipLaunchKernelGGL((k_tail_bg<5, 21, 5, 67>), dim3(b->bg_cus), dim3(256), b->tail_lds, b->stream_bg, t, g);
             HIPCHK(hipGetLastError());
