@@ -268,16 +268,24 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     // combinations + stage 2 for stage-1 output P20 (0..19) of a body
     auto post = [&](auto p20_tag, const Acc &c) {
         constexpr int P20 = decltype(p20_tag)::value;
+        // (the combinations below are inline assembly: the compiler does not space them from the MFMAs that write their sources.
+        // In phases 0..8 the next phase's 21 operand reads stand in between; the last phase of a half-body has none: 12 wait states)
+        if constexpr (P20 % 10 == 9) asm volatile("s_nop 7\n\ts_nop 3");
         // channel A = the slot's own table: (Pr - Qi) + j (Pi + Qr); channel B = its conjugate: (Pr + Qi) + j (Pi - Qr)
         v2f Y[8];
 #pragma unroll
         for (int g = 0; g < 2; g++)
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                const float Pr = c.Dr[g][2 * e], Qr = c.Dr[g][2 * e + 1], Pi = c.Di[g][2 * e], Qi = c.Di[g][2 * e + 1];
-                Y[4 * g + 2 * e] = v2f{Pr - Qi, Pi + Qr};
-                Y[4 * g + 2 * e + 1] = v2f{Pr + Qi, Pi - Qr};
+                // one packed add per channel: sources (Pr, Qr) and (Pi, Qi) as the accumulators hold them; the low half takes the
+                // second source's HIGH half (op_sel) and the high half its LOW half (op_sel_hi), negated where the sign says so --
+                // (Pr - Qi, Qr + Pi) and (Pr + Qi, Pi - Qr), the same additions the two scalar instructions per half made
+                const v2f pq_r = {c.Dr[g][2 * e], c.Dr[g][2 * e + 1]};
+                const v2f pq_i = {c.Di[g][2 * e], c.Di[g][2 * e + 1]};
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(Y[4 * g + 2 * e]) : "v"(pq_r), "v"(pq_i));
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(Y[4 * g + 2 * e + 1]) : "v"(pq_r), "v"(pq_i));
             }
+        asm volatile("s_nop 0");                                 // (a packed instruction may read what the last one above wrote)
         // stage-2 output j (absolute) has the stage-1 outputs 5j-14 .. 5j+4 as its window (S::addSample fires on every
         // 5th input, msd.hpp:228-247).  Inside a body, input u = P20 % 5 of super-step s = P20 / 5 is element 14 + u - 5 dd
         // of the window of output s + dd: output s + 3 starts at u = 1 (element 0), output s completes at u = 4 (element 18)
