@@ -1553,8 +1553,8 @@ __device__ __forceinline__ void tail_stream_unit(const TailArgs &a, const int ch
 }
 
 template <int MA, int TA, int MB, int TB, int NB, int DEPTH>
-// (launch bounds: 5 waves per SIMD as the register budget = 102 VGPRs; two waves of k_stage12m's lean build, 208 each, leave 96)
-__global__ __launch_bounds__(256, 5) void k_tail_bgs(const TailArgs a, const BgArgs g)
+// (launch bounds: 6 waves per SIMD as the register budget = 80 VGPRs: what two waves of k_stage12m's lean build, 216 each, leave)
+__global__ __launch_bounds__(256, 6) void k_tail_bgs(const TailArgs a, const BgArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     __shared__ int s_idx;

@@ -1174,6 +1174,24 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 free_bank(b);
                 return fail(SDRXGPU_ERR_HIP, "k_tail_bg set-up failed: %s", hipGetErrorString(e));
             }
+            // The scheme rests on two waves of k_stage12m's lean build and one of the background kernel sharing a SIMD's 512
+            // registers (granules of 8): with a build in which they do not, the background workgroup would take the place of a
+            // k_stage12m workgroup on every CU -- measured 0.93 against 0.86 ms per block.  Checked, not assumed.
+            {
+                hipFuncAttributes am{}, ab{}, ac{};
+                const void *fm = b->mGS == 2 && b->mGT == 2 ? reinterpret_cast<const void *>(&k_stage12m<2, 2, true>)
+                               : b->mGS == 4 ? reinterpret_cast<const void *>(&k_stage12m<4, 2, true>) : reinterpret_cast<const void *>(&k_stage12m<2, 4, true>);
+                e = hipFuncGetAttributes(&am, fm);
+                if (e == hipSuccess) e = hipFuncGetAttributes(&ab, reinterpret_cast<const void *>(&k_tail_bgs<5, 21, 5, 67, SDRX_BGS_NB, SDRX_BGS_DEPTH>));
+                if (e == hipSuccess) e = hipFuncGetAttributes(&ac, reinterpret_cast<const void *>(&k_tail_bg<5, 21, 5, 67>));
+                const int gm = (am.numRegs + 7) / 8 * 8, gb = (std::max(ab.numRegs, ac.numRegs) + 7) / 8 * 8;
+                const int waves_m = 2;                                      // waves of k_stage12m per SIMD (two workgroups of 4 waves or one of 8 per CU)
+                if (e != hipSuccess || waves_m * gm + gb > 512) {
+                    free_bank(b);
+                    return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.bg_tail = 2, but this build's kernels do not share a SIMD (%d x %d + %d registers)",
+                                waves_m, gm, gb);
+                }
+            }
             b->bg_cus = tune.bg_wgs ? (int)std::min<uint32_t>(tune.bg_wgs, 4096u) : (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
             b->bg_target = 0;
         }
