@@ -57,7 +57,7 @@ struct Stage12mTaps {
 // A wave's memory instructions -- LDS-DMA for the next half-body, stores of the previous one's outputs -- go out a piece per phase
 // instead of in a burst behind the barrier (-5 % on the launch).  LEAN = false (the ordinary launch): also, the first six phases of
 // a lane's warm-up body (nobody's input) are skipped (-1.5 %): a second path through the half-body, 256 VGPRs and a few spills.
-// LEAN = true: not that; 206 VGPRs, what the launch beside k_tail_bg / k_tail_bgs may have (two of these waves and one of theirs
+// LEAN = true: not that, and the DMA row offsets as scalars; 212 VGPRs, what the launch beside k_tail_bg / k_tail_bgs may have (two of these waves and one of theirs
 // per SIMD: 2 x 216 + 80).
 template <int GS, int GT, bool LEAN>
 __global__ __launch_bounds__(64 * GS * GT, 2)

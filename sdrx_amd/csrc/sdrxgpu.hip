@@ -318,7 +318,7 @@ static hipError_t launch_k12m_one(const K12mLaunch &M, const Stage12mTaps &taps,
     return hipGetLastError();
 }
 
-// `lean`: the 206-VGPR build (whole warm-up body) that leaves a SIMD room for a wave of k_tail_bg beside two of its own
+// `lean`: the 212-VGPR build (whole warm-up body, scalar DMA offsets) that leaves a SIMD room for a wave of k_tail_bg beside two of its own
 static hipError_t launch_k12m(const K12mLaunch &M, bool lean, hipStream_t s)
 {
     Stage12mTaps taps{};
