@@ -182,6 +182,51 @@ __device__ __forceinline__ v2f folded_fir_unrolled(const v2f *__restrict__ w, co
     return acc;
 }
 
+// The same with the window's LDS reads issued D tap pairs AHEAD of their use: left to the compiler, the reads of a folded FIR over
+// a window in LDS come one pair at a time in front of the add that needs them (it schedules for few registers), and a 67-tap
+// output is 33 LDS round trips in a row -- 2 000-2 400 cycles per tile of k_tail_s (in-kernel stamps), with one wave of the
+// workgroup active.  Volatile reads in their own address space keep their place (and stay single ds_read_b64).  Same operands,
+// same order, same bits as folded_fir_unrolled.
+#ifndef SDRX_FIR_AHEAD_A
+#define SDRX_FIR_AHEAD_A 5
+#endif
+#ifndef SDRX_FIR_AHEAD_B
+#define SDRX_FIR_AHEAD_B 8
+#endif
+typedef const volatile __attribute__((address_space(3))) v2f lds_cv2f_t;
+__device__ __forceinline__ v2f lds_read_here(const v2f *p) { return *(lds_cv2f_t *)(uint32_t)(uintptr_t)p; }
+
+template <int T, int NH, int D, int I = 0>
+__device__ __forceinline__ void folded_fir_ahead_steps(v2f &acc, v2f (&lo)[D], v2f (&hi)[D], const v2f *__restrict__ w, const float (&h)[NH])
+{
+    constexpr int half = (T - 1) >> 1;
+    if constexpr (I <= half) {
+        const v2f hp = {h[I & ~1], h[(I & ~1) + 1]};
+        if constexpr (I < half) {
+            const v2f s = lo[I % D] + hi[I % D];
+            if constexpr (I + D < half) { lo[I % D] = lds_read_here(w + I + D); hi[I % D] = lds_read_here(w + T - 1 - I - D); }
+            else if constexpr (I + D == half) { lo[I % D] = lds_read_here(w + half); }
+            fma_tap<I>(acc, s, hp);
+        } else {
+            fma_tap<I>(acc, lo[I % D], hp);
+        }
+        folded_fir_ahead_steps<T, NH, D, I + 1>(acc, lo, hi, w, h);
+    }
+}
+
+template <int T, int NH, int D>
+__device__ __forceinline__ v2f folded_fir_ahead(const v2f *__restrict__ w, const float (&h)[NH])
+{
+    constexpr int half = (T - 1) >> 1;
+    static_assert(D >= 1 && D <= half, "prefetch distance in tap pairs");
+    v2f lo[D], hi[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) { lo[i] = lds_read_here(w + i); hi[i] = lds_read_here(w + T - 1 - i); }
+    v2f acc = {0.f, 0.f};
+    folded_fir_ahead_steps<T, NH, D>(acc, lo, hi, w, h);
+    return acc;
+}
+
 // Two outputs at once (windows w0 and w1, same taps): the two accumulation chains alternate, so neither packed FMA
 // reads the result of the instruction before it and one wait state serves both (fma_tap spends one per tap).  Per
 // output the same instruction sequence on the same operands as folded_fir_unrolled: bit-identical results.
@@ -1280,7 +1325,7 @@ __device__ __forceinline__ void tail_s_unit(const TailArgs &a, const int ch, con
 
     const v2f *bsrc = s2;
     if constexpr (HAS_A) {
-        for (int r = tid; r < nr; r += 256) s3[r] = folded_fir_unrolled<TA>(s2 + MA * r, a.hA);
+        for (int r = tid; r < nr; r += 256) s3[r] = folded_fir_ahead<TA, kMaxHalfTaps, SDRX_FIR_AHEAD_A>(s2 + MA * r, a.hA);
         __syncthreads();
         bsrc = s3;
     }
@@ -1288,7 +1333,7 @@ __device__ __forceinline__ void tail_s_unit(const TailArgs &a, const int ch, con
     // one wave's work, the other waves are done (k_tail splits an output over two lanes: more parallel, but three
     // times the issue slots, and issue slots are what this kernel runs out of)
     if (tid < nbt) {
-        const v2f r = folded_fir_unrolled<TB>(bsrc + MB * tid, a.hB);
+        const v2f r = folded_fir_ahead<TB, kMaxHalfTaps, SDRX_FIR_AHEAD_B>(bsrc + MB * tid, a.hB);
         const float2 o = make_float2(r.x, r.y);
         if (a.iq_out) a.iq_out[(size_t)ch * a.out_stride + s0 + tid] = o;
         if (a.iq_keep) a.iq_keep[(size_t)ch * a.keep_stride + s0 + tid] = o;
