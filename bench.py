@@ -352,10 +352,10 @@ def main():
     pair_seen = {}
     matrix_seen = {}
 
-    def run(offsets, steps, warmup, events=True):
+    def run(offsets, steps, warmup, events=True, tuning_override=None):
         tabs = sb.translators_for(ch, offsets)
         bank = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, stream=tstream.cuda_stream, block_hint=args.block_hint,
-                              pipelined=args.pipelined, tuning=tuning)
+                              pipelined=args.pipelined, tuning=tuning_override or tuning)
         fused_seen[len(offsets)] = int(bank.info().fused_tail)
         pair_seen[len(offsets)] = int(bank.info().pair_lanes)
         matrix_seen[len(offsets)] = int(bank.info().matrix_pipe)
@@ -391,6 +391,18 @@ def main():
             extra[name] = {"value": len(o) * L * max(10, args.steps) / dte / 1e6, "unit": "Mch-samples/s",
                            "ms_per_step": dte / max(10, args.steps) * 1e3, "realtime_factor": L * max(10, args.steps) / dte / ch.fs,
                            "kernel_ms_avg": {n: v[0] for n, v in ke.items()}, "fused_tail": fused_seen[len(o)]}
+
+    if world == 1 and not args.no_extra_configs and tuning is None and matrix_seen.get(n_ch):
+        # the same workload with the tail stages BESIDE the stage-1/2 kernel (tuning.bg_tail = 2, DESIGN 4.8: opt-in; 1 to 3.4 %
+        # over the boxes tried; needs the runtime to run two launches of the process at once)
+        try:
+            dtb, kb = run(offs, max(30, args.steps), args.warmup, tuning_override={"bg_tail": 2})
+            nb_steps = max(30, args.steps)
+            extra["the workload with tuning.bg_tail = 2 (tail stages beside the stage-1/2 kernel, opt-in)"] = {
+                "value": n_ch * L * nb_steps / dtb / 1e6, "unit": "Mch-samples/s", "ms_per_step": dtb / nb_steps * 1e3,
+                "realtime_factor": L * nb_steps / dtb / ch.fs, "kernel_ms_avg": {n: v[0] for n, v in kb.items()}}
+        except sb.SdrxGpuError as e:
+            extra["the workload with tuning.bg_tail = 2 (tail stages beside the stage-1/2 kernel, opt-in)"] = {"refused": str(e)}
 
     if world == 1 and not args.no_extra_configs:
         # BASELINE configs[4], one GPU's share: 2 independent 10 MS/s streams x 1024 channels, each stream's block
