@@ -177,3 +177,25 @@ def test_device_entry_reads_the_callers_iq_rows_in_place_squelch_and_fm(stride, 
         assert np.array_equal(giq.view(np.uint32), riq.view(np.uint32))
         assert np.array_equal(gau.view(np.uint32), rau.view(np.uint32))
     b.close()
+
+
+def test_creating_and_destroying_banks_returns_their_device_memory():
+    """A loop of create / host-pointer call / destroy, nothing in between: the device's free memory must not shrink (it did, by a
+    bank's translator tables per round -- 62 MB of a 3 000-channel bank -- until bank_create waited for its own uploads)."""
+    ch = chains.chain("10")
+    n_ch = 2000
+    tabs = sb.translators_for(ch, chains.offsets_cycled(n_ch, ch.N))
+    x = synth.synth_iq(3, 0, ch.block_len, 0.25)
+
+    def one():
+        bank = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": 1})
+        bank.process(x)
+        bank.close()
+    one()                                                   # (the runtime's own first-use allocations)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(8):
+        one()
+    torch.cuda.synchronize()
+    lost = free0 - torch.cuda.mem_get_info()[0]
+    assert lost < 16 << 20, "%d MB of device memory not returned by 8 banks" % (lost >> 20)
