@@ -4,7 +4,7 @@ per lane, stage 3 fused, IQ rows read in place -- whatever bank_create picks) ag
 tail, bit for bit; half of the cases also through the device-pointer entry with the caller's rows at a random stride; and
 three channels of every case against the oracle (1e-5); all nine chains, --ftfir on the two 4-stage ones.  Round 2:
 10 355 + 5 487 + 4 193 + 8 387 cases in 240 + 150 + 120 + 200 s on one MI355X (a third of the 10 MS/s cases on the
-fused path), no failure."""
+fused path), no failure; round 3, final build: 18 567 cases in 420 s (seed 13), no failure."""
 import os
 import random
 import sys
