@@ -2,6 +2,8 @@
 # collect a round's evidence on the GPU box: gpurun -- tools/collect_evidence.sh  (outputs under gpurun_out/ev/, copied into
 # profiles/ by tools/publish_evidence.sh).  Every GPU step runs under a time limit; a step killed at its limit (a hang)
 # ends the script: no further GPU process after it.
+# The microbenchmarks it runs are built beforehand, here (no GPU needed):
+#   for f in valu hbm_read mfma_fir corun; do hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/ubench_$f.bin tools/ubench_$f.hip; done
 set -u
 cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=8      # (what bench.py sets for itself; under rocprofv3 the runtime starts before the program does)
