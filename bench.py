@@ -7,7 +7,13 @@ AM envelope (-> LF-AGC), i.e. the reference's data_cb channel loop (src/sdrx.cpp
 alsa_write_cb's per-sample lines (455-463).  Metric (BASELINE.json): IQ Msamples/s ingested x
 channels demodulated = million channel-samples per second, whole job.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--channels C]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--channels C] [--config headline|c4|c5]
+
+--config: headline (default) = north_star's target, C channel instances per GPU from one stream; c4 = BASELINE configs[3]
+(8 192 channels = 1 024 per GPU from one stream, block broadcast); c5 = BASELINE configs[4] (16 independent streams x 1 024
+channels = 2 banks per GPU, blocks from page-locked host memory, no broadcast).  Same JSON contract for all three;
+config.workload names the configuration.  Outside the timed region every rank checks the blocks it received against
+the generator (input_check in the JSON line; a wrong block makes the run fail).
 
 N > 1: one rank per GPU over RCCL.  Started as `python bench.py --gpus N` this process touches no GPU: it
 starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's JSON line
@@ -40,6 +46,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=10000, help="channel instances per GPU")
+    ap.add_argument("--config", choices=("headline", "c4", "c5"), default="headline",
+                    help="headline: --channels instances per GPU from one stream; c4 / c5: BASELINE configs[3] / configs[4] (see module docstring)")
     ap.add_argument("--rate", default="10")
     ap.add_argument("--block-hint", type=int, default=0)
     ap.add_argument("--fused", type=int, default=0, help="tuning.fused_tail: 0 auto, 1 separate tail kernel, 2 require the fused path")
@@ -185,53 +193,76 @@ def cpu_baseline(chain, seconds=12.0):
 # launcher / fan-out self-test (CPU, gloo)
 # ------------------------------------------------------------------------------------------------
 def selftest_launch(args):
-    """What `--gpus N` does around the channelizer, without a GPU: N gloo ranks, the double-buffered fan-out of the
-    IQ blocks, the barrier / max-over-ranks timing and rank 0's JSON line.  No channelizer work (value = 0)."""
+    """What `--gpus N` does around the channelizer, without a GPU: N gloo ranks, the configuration's plan (which channels,
+    which streams on which rank), the double-buffered fan-out of the IQ blocks (headline / c4) or the ranks' own streams
+    (c5), every received block checked against the generator, the barrier / max-over-ranks timing and rank 0's JSON
+    line.  No channelizer work (value = 0)."""
     import numpy as np
     import torch
     import torch.distributed as dist
+    from sdrx_amd import chains
     from sdrx_amd import dist as sdist
     from sdrx_amd import synth
     rank, _, world = sdist.env_rank_world()
     dist.init_process_group("gloo")
+    ch = chains.chain(args.rate)
+    plan = sdist.plan(args.config, rank, world, ch.N, args.channels)
     L = 4096
-    bufs = [torch.empty(L, 2), torch.empty(L, 2)]
-    fan = sdist.PipelinedFanout(dist, bufs, src=0)
-
-    def block(k):
-        return torch.from_numpy(synth.synth_iq(7, k * L, L, 0.25).view(np.float32).reshape(L, 2).copy())
-
     steps = args.steps
-    fan.post(0, block(0) if rank == 0 else None)
+
+    def block(seed, k):
+        return torch.from_numpy(synth.synth_iq(seed, k * L, L, 0.25).view(np.float32).reshape(L, 2).copy())
+
+    bad = checked = 0
     dist.barrier()
     t0 = time.perf_counter()
-    bad = 0
-    for k in range(steps):
-        cur = fan.get(k)
-        if k + 1 < steps:
-            fan.post(k + 1, block(k + 1) if rank == 0 else None)
-        bad += int(not torch.equal(cur, block(k)))           # every rank regenerates the block it should have received
-        fan.done(k)
+    if plan.broadcast:
+        bufs = [torch.empty(L, 2), torch.empty(L, 2)]
+        fan = sdist.PipelinedFanout(dist, bufs, src=0)
+        fan.post(0, block(7, 0) if rank == 0 else None)
+        for k in range(steps):
+            cur = fan.get(k)
+            if k + 1 < steps:
+                fan.post(k + 1, block(7, k + 1) if rank == 0 else None)
+            # every rank regenerates the block it should have received and compares checksums
+            bad += int(sdist.block_checksum(cur) != sdist.block_checksum(block(7, k)))
+            checked += 1
+            fan.done(k)
+    else:
+        # every bank has a stream of its own, generated where it is consumed: nothing crosses ranks.  What is checked: the
+        # seeds of the job's streams are all different and each arrives in its bank's buffer unchanged
+        rings = [torch.empty(L, 2) for _ in plan.seeds]
+        for k in range(steps):
+            for i, seed in enumerate(plan.seeds):
+                rings[i].copy_(block(seed, k))
+                bad += int(sdist.block_checksum(rings[i]) != sdist.block_checksum(block(seed, k)))
+                checked += 1
+        seeds = [None] * world
+        dist.all_gather_object(seeds, plan.seeds)
+        flat = [x for sub in seeds for x in sub]
+        bad += int(len(set(flat)) != len(flat) or sorted(flat) != list(range(1, 2 * world + 1)))
     dist.barrier()
     dt = sdist.max_over_ranks(dist, time.perf_counter() - t0)
-    t = torch.tensor([bad], dtype=torch.int64)
+    t = torch.tensor([bad, checked, plan.channels_per_gpu], dtype=torch.int64)
     dist.all_reduce(t)
     if rank == 0:
         print(json.dumps({"metric": "IQ Msamples/s ingested x channels demodulated (channel-samples/s)", "value": 0.0,
                           "unit": "Mch-samples/s", "n_gpus": world, "steps": steps, "warmup": 0, "ms_per_step": dt / steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "selftest: launcher + double-buffered block fan-out only (gloo, CPU)",
-                                     "parallelism": f"{world} gloo ranks"},
-                          "selftest": {"blocks_received_wrong": int(t.item())}}), flush=True)
+                          "config": {"workload": "selftest (gloo, CPU; launcher, plan, block transport and input check only) of: " + plan.workload,
+                                     "name": plan.name, "channels_total": int(t[2].item()), "parallelism": plan.parallelism + f" ({world} gloo ranks)"},
+                          "input_check": {"blocks_checked": int(t[1].item()), "blocks_wrong": int(t[0].item())},
+                          "selftest": {"blocks_received_wrong": int(t[0].item())}}), flush=True)
     dist.destroy_process_group()
-    sys.exit(1 if int(t.item()) else 0)
+    sys.exit(1 if int(t[0].item()) else 0)
 
 
 # ------------------------------------------------------------------------------------------------
 # rank mode
 # ------------------------------------------------------------------------------------------------
-def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch, events=True):
-    """SETTLE + W untimed steps, then exactly `steps` timed steps bracketed by synchronize + barrier.
+def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch, events=True, expect=None, check=None):
+    """An input-check pass (expect: the generator's checksum of every ring block, known to every rank; check: dict that
+    takes the counts), SETTLE + W untimed steps, then exactly `steps` timed steps bracketed by synchronize + barrier.
     events: HIP events around the dominant kernel inside the timed region (the headline configuration: roofline.achieved
     comes from them; they cost ~5 us per step, which a 1 ms step does not notice and a 0.05 ms step does)."""
     state = {"k": 0}
@@ -240,6 +271,19 @@ def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring,
         return ring[k % n_ring] if rank == 0 else None
 
     fan.post(0, block_for(0))
+
+    # Input check, outside the timed region: every block of the ring travels the way the timed blocks do (rank 0's ring ->
+    # fan-out -> this rank's bank input ring) and every rank compares the checksum of what ARRIVED with the generator's.
+    if expect is not None:
+        for _ in range(n_ring):
+            k = state["k"]
+            cur = fan.get(k)
+            fan.post(k + 1, block_for(k + 1))
+            got = sdist.block_checksum(cur.cpu())           # (synchronises the current stream: the block has arrived)
+            check["blocks_checked"] += 1
+            check["blocks_wrong"] += int(got != expect[k % n_ring])
+            fan.done(k)
+            state["k"] = k + 1
 
     def step():
         k = state["k"]
@@ -293,6 +337,103 @@ def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring,
     return dt, k
 
 
+def run_c5(args, plan, ch, rank, local_rank, world, dist, torch, np, sb, sdist, synth):
+    """BASELINE configs[4]: every rank drives 2 banks of 1 024 channels, each from an IQ stream of its own that arrives from
+    page-locked host memory (sdrxgpu_bank_process_pinned: the H2D copy of a bank's next block runs on its copy stream beside
+    the other bank's kernels).  No broadcast, nothing between GPUs; a step = one block through BOTH banks of every rank."""
+    L = ch.block_len
+    n_host = 4                                                     # distinct page-locked blocks per stream, used in turn
+    banks, hosts, outs, expect = [], [], [], []
+    for offs, seed in zip(plan.offsets, plan.seeds):
+        tabs = sb.translators_for(ch, offs)
+        banks.append(sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank))
+        blocks = [synth.synth_iq(seed, b * L, L, 0.25).view(np.float32).reshape(L, 2).copy() for b in range(n_host)]
+        expect.append([sdist.block_checksum(b_) for b_ in blocks])
+        hosts.append([torch.from_numpy(b_).pin_memory() for b_ in blocks])
+        outs.append((torch.empty(len(offs), 512, 2, device="cuda"), torch.empty(len(offs), 512, device="cuda")))
+    state = {"k": 0}
+
+    def step():
+        k = state["k"]
+        for i, bk in enumerate(banks):
+            n = bk.process_pinned(hosts[i][k % n_host].data_ptr(), L, outs[i][0].data_ptr(), outs[i][1].data_ptr(), 512)
+            assert n == 512
+        state["k"] = k + 1
+
+    # input check, outside the timed region: what arrived in each bank's input ring against the generator
+    check = {"blocks_checked": 0, "blocks_wrong": 0}
+    for _ in range(n_host):
+        k = state["k"]
+        where = [bk.ingest_buffer()[0] for bk in banks]            # where the NEXT block of each bank will be written
+        step()
+        for i, bk in enumerate(banks):
+            bk.synchronize()
+            got = torch.as_tensor(sb.DeviceView(where[i], (L, 2)), device="cuda").cpu()
+            check["blocks_checked"] += 1
+            check["blocks_wrong"] += int(sdist.block_checksum(got) != expect[i][k % n_host])
+    for _ in range(SETTLE_STEPS + args.warmup):
+        step()
+    for bk in banks:
+        bk.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    banks[0].profile_reset()
+    banks[0].profile_enable(2)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    for bk in banks:
+        bk.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = sdist.max_over_ranks(dist, time.perf_counter() - t0, device="cuda")
+    k12_ms, k12_n = banks[0].profile_read(sb.K_STAGE12)
+    k12_ms /= max(k12_n, 1)
+    banks[0].profile_enable(0)
+    infos = [bk.info() for bk in banks]
+    for i, bk in enumerate(banks):
+        assert bool(torch.isfinite(outs[i][0]).all()) and bool(torch.isfinite(outs[i][1]).all())
+        bk.close()
+    n_wrong = check["blocks_wrong"]
+    if dist is not None:
+        tw = torch.tensor([check["blocks_checked"], check["blocks_wrong"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tw)
+        check = {"blocks_checked": int(tw[0].item()), "blocks_wrong": int(tw[1].item())}
+        n_wrong = check["blocks_wrong"]
+    check["how"] = "every rank: checksum of its banks' blocks as they arrived in the banks' input rings (H2D from page-locked memory) against the generator's"
+    if rank == 0:
+        n_bank = len(plan.offsets[0])
+        units = float(n_bank) * L
+        f12 = flops_per_channel_sample(ch, 3 if infos[0].fused_tail else 2)
+        ach = f12 * units / (k12_ms / 1e3) / 1e12 if k12_n else None
+        value = float(plan.channels_total) * L * args.steps / dt / 1e6
+        out = {
+            "metric": "IQ Msamples/s ingested x channels demodulated (channel-samples/s)", "value": value, "unit": "Mch-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": plan.workload + f"; {args.rate} MS/s, 32 ms blocks of {L} complex<float>, mixer + 4-stage FIR "
+                                   f"decimation /{ch.m_total} + IF-AGC + AM envelope",
+                       "name": plan.name, "channels_per_gpu": plan.channels_per_gpu, "channels_total": plan.channels_total,
+                       "streams_per_gpu": len(plan.seeds), "sample_rate": ch.fs, "block_len": L, "parallelism": plan.parallelism,
+                       "includes": "PCIe H2D of every block (the configuration is about that overlap; inputs are NOT resident in HBM "
+                                   "when a step starts -- unlike the headline line)",
+                       "realtime_factor": value * 1e6 / (plan.channels_total * ch.fs),
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "settle_steps": SETTLE_STEPS},
+            "roofline": {"bound": "valu_fp32", "kernel": "k_stage12p (one bank's launch while the other bank's kernels share the chip)",
+                         "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF if ach else None,
+                         "flops_per_unit": f12, "traffic": None, "launches": int(k12_n),
+                         "whole_step_tflops": flops_per_channel_sample(ch, len(ch.stages)) * units * len(plan.seeds) / (dt / args.steps) / 1e12},
+            "input_check": check,
+            "cpu_baseline": cpu_baseline(ch, args.cpu_seconds) if (world == 1 and not args.no_cpu_baseline) else None,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    sys.exit("input check failed: %d block(s) arrived different from what the generator made" % n_wrong if n_wrong else 0)
+
+
 def main():
     args = parse_args()
     launched = "WORLD_SIZE" in os.environ
@@ -328,7 +469,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ch = chains.chain(args.rate)
-    n_ch = args.channels
+    plan = sdist.plan(args.config, rank, world, ch.N, args.channels)
+    if plan.name == "c5":
+        run_c5(args, plan, ch, rank, local_rank, world, dist, torch, np, sb, sdist, synth)       # does not return
+    n_ch = plan.channels_per_gpu
     L = ch.block_len
     # one explicit (non-default) torch stream carries the bank's kernels and the ring copies; the RCCL broadcast of
     # the NEXT block runs on the fan-out's own stream beside them
@@ -338,10 +482,13 @@ def main():
     # synthetic IQ stream: a ring of distinct 32 ms blocks in HBM on rank 0 (uniform noise + 2 AM carriers)
     n_ring = 8
     ring = None
+    car = [sb.make_translator(ch.N, ch.z, o) for o in (5, -20)]
+    # (every rank generates the ring: rank 0 to send it, the others to know what they should receive)
+    host = np.stack([synth.synth_iq(1234, b * L, L, 0.25, car, [0.3, 0.1], ch.N, ch.fs // 1000).view(np.float32).reshape(L, 2)
+                     for b in range(n_ring)])
+    expect = [sdist.block_checksum(host[b]) for b in range(n_ring)]
+    check = {"blocks_checked": 0, "blocks_wrong": 0}
     if rank == 0:
-        car = [sb.make_translator(ch.N, ch.z, o) for o in (5, -20)]
-        host = np.stack([synth.synth_iq(1234, b * L, L, 0.25, car, [0.3, 0.1], ch.N, ch.fs // 1000).view(np.float32).reshape(L, 2)
-                         for b in range(n_ring)])
         ring = torch.from_numpy(host).cuda()
 
     tuning = None
@@ -352,7 +499,7 @@ def main():
     pair_seen = {}
     matrix_seen = {}
 
-    def run(offsets, steps, warmup, events=True, tuning_override=None):
+    def run(offsets, steps, warmup, events=True, tuning_override=None, checked=False):
         tabs = sb.translators_for(ch, offsets)
         bank = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, stream=tstream.cuda_stream, block_hint=args.block_hint,
                               pipelined=args.pipelined, tuning=tuning_override or tuning)
@@ -368,7 +515,8 @@ def main():
         d_iq = torch.empty(len(offsets), 512, 2, dtype=torch.float32, device="cuda")
         d_au = torch.empty(len(offsets), 512, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
-        dt, k = time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch, events=events)
+        dt, k = time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch, events=events,
+                          expect=expect if checked else None, check=check)
         if args.pipelined:
             assert bank.flush(d_iq.data_ptr(), d_au.data_ptr(), 512) == 512
             torch.cuda.synchronize()
@@ -377,13 +525,21 @@ def main():
         return dt, k
 
     # this rank's shard of the job's channel list (instances cycle through all N distinct offsets; never deduplicated)
-    offs = sdist.shard_list(chains.offsets_cycled(n_ch * world, ch.N), rank, world)
+    offs = plan.offsets[0]
     assert len(offs) == n_ch
-    dt, k = run(offs, args.steps, args.warmup)
+    dt, k = run(offs, args.steps, args.warmup, checked=True)
+    n_wrong = check["blocks_wrong"]
+    if dist is not None:
+        tw = torch.tensor([check["blocks_checked"], check["blocks_wrong"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tw)
+        check = {"blocks_checked": int(tw[0].item()), "blocks_wrong": int(tw[1].item())}
+        n_wrong = check["blocks_wrong"]
+    check["how"] = ("every rank: checksum of each of the ring's blocks as it arrived in the bank's input ring (rank 0's ring -> "
+                    "fan-out -> ingest buffer) against the generator's, before the settling steps")
     fused = fused_seen[n_ch]
 
     extra = {}
-    if world == 1 and not args.no_extra_configs:
+    if world == 1 and not args.no_extra_configs and plan.name == "headline":
         # BASELINE.json's other single-GPU configurations, same step definition (parity-test sizes; short runs)
         for name, key in (("64 channels, 8.33 kHz grid (configs[1])", "c2"), ("1024 channels, mixed 8.33/25 kHz (configs[2])", "c3")):
             o = chains.offsets_for_config(key)
@@ -392,7 +548,7 @@ def main():
                            "ms_per_step": dte / max(10, args.steps) * 1e3, "realtime_factor": L * max(10, args.steps) / dte / ch.fs,
                            "kernel_ms_avg": {n: v[0] for n, v in ke.items()}, "fused_tail": fused_seen[len(o)]}
 
-    if world == 1 and not args.no_extra_configs and tuning is None and matrix_seen.get(n_ch):
+    if world == 1 and not args.no_extra_configs and plan.name == "headline" and tuning is None and matrix_seen.get(n_ch):
         # the same workload with the tail stages BESIDE the stage-1/2 kernel (tuning.bg_tail = 2, DESIGN 4.8: opt-in; 1 to 3.4 %
         # over the boxes tried; needs the runtime to run two launches of the process at once)
         try:
@@ -404,7 +560,7 @@ def main():
         except sb.SdrxGpuError as e:
             extra["the workload with tuning.bg_tail = 2 (tail stages beside the stage-1/2 kernel, opt-in)"] = {"refused": str(e)}
 
-    if world == 1 and not args.no_extra_configs:
+    if world == 1 and not args.no_extra_configs and plan.name == "headline":
         # BASELINE configs[4], one GPU's share: 2 independent 10 MS/s streams x 1024 channels, each stream's block
         # arriving from pinned host memory: sdrxgpu_bank_process_pinned enqueues the H2D copy into the bank's free input
         # ring on the bank's copy stream and the kernels behind it, and returns without waiting
@@ -438,7 +594,7 @@ def main():
             bk.close()
 
     host_path = None
-    if world == 1 and not args.no_extra_configs:
+    if world == 1 and not args.no_extra_configs and plan.name == "headline":
         # the drop-in entry (host pointers in and out, outputs complete on return): PCIe-inclusive, NOT `value`
         tabs = sb.translators_for(ch, offs)
         hb = sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, tuning=tuning)
@@ -505,12 +661,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{n_ch} channel instances per GPU from one {args.rate} MS/s IQ stream, 8.33 kHz grid "
-                            f"(offsets cycle through all {ch.N} translator steps), 32 ms blocks of {L} complex<float>, "
+                "workload": plan.workload + f"; {args.rate} MS/s, 32 ms blocks of {L} complex<float>, "
                             f"mixer + 4-stage FIR decimation /{ch.m_total} + IF-AGC + AM envelope",
-                "channels_per_gpu": n_ch, "channels_total": n_ch * world, "sample_rate": ch.fs, "block_len": L,
+                "name": plan.name,
+                "channels_per_gpu": n_ch, "channels_total": plan.channels_total, "sample_rate": ch.fs, "block_len": L,
                 "outputs_per_channel_per_block": 512,
-                "parallelism": f"channel-sharded over {world} RCCL rank(s)" +
+                "parallelism": plan.parallelism +
                                (", block k+1 broadcast over xGMI into the banks' other input ring while block k is processed"
                                 if (world > 1 or args.force_dist) else ""),
                 "kernel_path": ("stage 3 fused behind stages 1-2 (k_stage12 + k_tail4 + k_agc)" if fused else
@@ -534,8 +690,12 @@ def main():
                 "frac": ach_tf / FP32_PEAK_TF if ach_tf else None,
                 "flops_per_unit": f12, "flops_per_unit_whole_step": f_all,
                 "whole_step_tflops": f_all * units / (dt / args.steps) / 1e12,
+                # HBM bytes per launch of the dominant kernel / per step (all three kernels), from the COMMITTED rocprofv3 --pmc
+                # passes of this build (tools_pmc.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes) -- not measured in this run
                 "traffic": prof.get("k_stage12_hbm_bytes_per_launch") if prof else None,
-                "traffic_source": prof_src,
+                "traffic_step": (sum(prof[kk]["hbm_bytes_per_launch"] for kk in ("k_stage12", "k_tail", "k_agc") if kk in prof)
+                                 if prof and "k_tail" in prof else None),
+                "traffic_source": ("committed profile profiles/" + prof_src + " (rocprofv3 --pmc passes of this build, not this run)") if prof_src else None,
                 "sustained_clock_ghz": prof.get("sustained_clock_ghz") if prof else None,
                 "launches": int(k12_n),
                 "kernels": kern,
@@ -550,6 +710,7 @@ def main():
                                     "ratio_to_hbm_peak_over_step": bpu * units / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             },
         }
+        out["input_check"] = check
         if extra:
             out["other_configs"] = extra
         if host_path:
@@ -561,6 +722,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if n_wrong:
+        sys.exit("input check failed: %d block(s) arrived different from what the generator made" % n_wrong)
 
 
 if __name__ == "__main__":

@@ -229,8 +229,15 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
             c.Dr[g] = v4f{r0.x, r0.y, r1.x, r1.y};
             c.Di[g] = v4f{i0.x, i0.y, i1.x, i1.y};
         }
+        // K steps in the order taps 0-3, 12-15, 4-7, 8-11: the small outer taps first, the large centre taps last, so that the
+        // partial sums a rounding is relative to stay small as long as possible (the reference's folded FIR adds outside-in
+        // too, msd.hpp:309-331).  Under a strong carrier every weak channel's P and Q are large sums that cancel; with the steps
+        // in natural order the weak partner's deviation from the reference was 1.7 x larger (strong carrier 0.9 over a floor
+        // of 0.05: 1.2e-5 of the channel's rms against 7.8e-6; tests/test_gpu_pairs_stress.py, DESIGN 4.7 "Numerics")
+        constexpr int korder[4] = {0, 3, 1, 2};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int jj = 0; jj < 4; jj++) {
+            const int j = korder[jj];
             const v2f x = o.x[j] * hA[j];                        // the tap rides on the B operand (shared by both half-groups)
             c.Dr[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ta[0][j], x.x, c.Dr[0], 0, 0, 0);
             c.Di[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ta[0][j], x.y, c.Di[0], 0, 0, 0);

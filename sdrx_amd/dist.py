@@ -30,6 +30,66 @@ def shard_list(items, rank: int, world: int):
     return items[lo:hi]
 
 
+class Plan:
+    """What one rank of a bench / job configuration runs: its banks (one offset list each), where each bank's IQ
+    stream comes from (broadcast from rank 0, or a stream of its own with this seed) and how the line is labelled."""
+
+    def __init__(self, name, workload, offsets, seeds, broadcast, channels_total, parallelism):
+        self.name = name
+        self.workload = workload
+        self.offsets = offsets            # one list of channel offsets per bank of this rank
+        self.seeds = seeds                # per bank: seed of its own IQ stream, or None (the broadcast stream)
+        self.broadcast = broadcast        # True: rank 0 owns the one stream, every block is broadcast
+        self.channels_total = channels_total
+        self.parallelism = parallelism
+
+    @property
+    def channels_per_gpu(self):
+        return sum(len(o) for o in self.offsets)
+
+
+def plan(config: str, rank: int, world: int, N: int, n_ch: int = 10000) -> "Plan":
+    """BASELINE.json's configurations as per-rank plans (reference dispatch src/sdrx.cpp:327-340,
+    src/ds.hpp:43-77: one independent worker per channel, so any partition of the channel list is valid).
+
+    headline: n_ch channel instances per GPU from ONE stream (weak scaling), offsets cycling through all N steps,
+              rank r takes instances [r n_ch, (r+1) n_ch); block broadcast.
+    c4:       configs[3] -- 8 192 channels = 1 024 per GPU (configs[2]'s offset set -512..511 on every GPU) from one
+              10 MS/s stream, the block broadcast to every GPU.  With world ranks: 1 024 x world channels.
+    c5:       configs[4] -- 16 independent streams x 1 024 channels on 8 GPUs = 2 banks per GPU, each bank with a stream
+              of its own (seeds 1..16: rank r has 2r+1 and 2r+2) arriving from page-locked host memory; NO broadcast,
+              no traffic between GPUs at all."""
+    from . import chains
+    if config == "headline":
+        offs = shard_list(chains.offsets_cycled(n_ch * world, N), rank, world)
+        return Plan("headline", f"{n_ch} channel instances per GPU from one IQ stream, 8.33 kHz grid (offsets cycle through all "
+                    f"{N} translator steps)", [offs], [None], True, n_ch * world,
+                    f"channel-sharded over {world} RCCL rank(s)")
+    if config == "c4":
+        o = chains.offsets_for_config("c3")
+        return Plan("c4", f"BASELINE configs[3]: {len(o) * world} channels from one 10 MS/s IQ stream, {len(o)} per GPU (configs[2]'s "
+                    "mixed 8.33/25 kHz offset set -512..511 on every GPU), per-GPU channel partition, the IQ block broadcast",
+                    [o], [None], True, len(o) * world, f"channel-sharded over {world} RCCL rank(s)")
+    if config == "c5":
+        o = chains.offsets_for_config("c3")
+        seeds = [2 * rank + 1, 2 * rank + 2]
+        return Plan("c5", f"BASELINE configs[4]: {2 * world} independent 10 MS/s IQ streams x {len(o)} channels each, 2 streams "
+                    "(banks) per GPU, every block H2D from page-locked host memory on the bank's copy stream beside the "
+                    "other bank's kernels (sdrxgpu_bank_process_pinned)", [o, o], seeds, False, 2 * len(o) * world,
+                    f"{2 * world} independent streams, 2 per GPU; no collective, no traffic between GPUs")
+    raise ValueError(f"unknown configuration {config!r} (headline, c4, c5)")
+
+
+def block_checksum(block) -> int:
+    """Order-sensitive 64-bit checksum of a block's bytes (numpy array or CPU torch tensor): what a rank compares with
+    the generator's to know that the block it received is the block that was sent."""
+    import numpy as np
+    a = np.ascontiguousarray(block.numpy() if hasattr(block, "numpy") else block).view(np.uint32).reshape(-1).astype(np.uint64)
+    w = (np.arange(a.size, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    with np.errstate(over="ignore"):
+        return int(np.bitwise_xor.reduce(a * w + (a << np.uint64(17))))
+
+
 class BlockFanout:
     """Rank ``src`` owns the IQ stream; every step its block is broadcast to all ranks.
 

@@ -23,8 +23,11 @@ def _splitmix64_at(seed: int, idx: np.ndarray) -> np.ndarray:
 
 
 def synth_iq(seed: int, n_start: int, n: int, noise_amp: float = 0.25, carriers=(), carrier_amp=(),
-             N: int = 1, tri_period: int = 10000) -> np.ndarray:
-    """Return ``n`` complex64 samples with absolute indices ``n_start .. n_start+n-1``."""
+             N: int = 1, tri_period: int = 10000, tri_depth: float = 0.5) -> np.ndarray:
+    """Return ``n`` complex64 samples with absolute indices ``n_start .. n_start+n-1``.
+
+    ``tri_depth``: modulation depth of the carriers' triangle AM (0.5 = the C twin's fixed value; the pair-stress
+    fixtures of tests/golden/pairs use shallower ones so that a carrier of mean amplitude A peaks at <= 1)."""
     abs_n = np.arange(n_start, n_start + n, dtype=np.uint64)
     scale = np.float32(1.0 / 8388608.0)
     amp = np.float32(noise_amp)
@@ -38,7 +41,7 @@ def synth_iq(seed: int, n_start: int, n: int, noise_amp: float = 0.25, carriers=
         d = np.abs(2 * v - P)
         tri_step = np.float32(2.0) / np.float32(P)
         tri = d.astype(np.float32) * tri_step - np.float32(1.0)
-        mod = np.float32(1.0) + np.float32(0.5) * tri
+        mod = np.float32(1.0) + np.float32(tri_depth) * tri
         tn = (abs_n % np.uint64(N)).astype(np.int64)
         for t, a in zip(carriers, carrier_amp):
             t = np.asarray(t, dtype=np.complex64)

@@ -44,9 +44,9 @@ def oracle():
     return ffi.load("oracle")
 
 
-def load_golden(name):
+def load_golden(name, subdir=None):
     import json
-    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    z = np.load(os.path.join(GOLD if subdir is None else os.path.join(GOLD, subdir), name + ".npz"), allow_pickle=False)
     d = {k: z[k] for k in z.files}
     d["meta"] = json.loads(str(d["meta"]))
     d["rate"] = str(d["rate"])
@@ -84,7 +84,7 @@ def regen_blocks(g):
                 from oracle import ffi
                 car.append(ffi.load("oracle").make_translator(ch.N, ch.z, o))
         x = synth.synth_iq(meta["seed"], 0, total, meta["noise_amp"], car, meta.get("carrier_amp", []), ch.N,
-                           meta.get("tri_period", ch.fs // 1000))
+                           meta.get("tri_period", ch.fs // 1000), meta.get("tri_depth", 0.5))
     assert hashlib.sha256(x.tobytes()).hexdigest() == g["input_sha256"], "regenerated input differs from the fixture's"
     blocks, p = [], 0
     for n in lens:

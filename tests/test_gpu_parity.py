@@ -2,6 +2,8 @@
 against the golden vectors produced by the compiled reference and against the oracle on
 identical seeded input.  Tolerance: 1e-5 relative under the comparator of conftest.rel_err
 (north_star: "within 1e-5 relative float tolerance")."""
+import os
+
 import numpy as np
 import pytest
 
@@ -196,8 +198,9 @@ def test_full_size_10k_channels_properties_and_sampled_oracle(oracle):
             assert np.array_equal(iq[c].view(np.uint32), iq[c + rep * ch.N].view(np.uint32))
             assert np.array_equal(au[c].view(np.uint32), au[c + rep * ch.N].view(np.uint32))
     # (2) sampled channels against the oracle (incl. the ends of the offset range and the tuner centre)
-    pick = sorted(set([0, 1, 2, 599, 600, 601, 1199, 1200, 4321, 9999] + list(range(37, n_ch, 997))))
-    ref_iq, ref_au = _oracle_bank(oracle, ch, [tabs[c] for c in pick], blocks, threads=8)
+    #     -- all 1 200 distinct offsets (channels 0 .. 1 199) and later instances spread over the bank
+    pick = sorted(set(list(range(ch.N)) + [ch.N, 4321, 9999] + list(range(37, n_ch, 997))))
+    ref_iq, ref_au = _oracle_bank(oracle, ch, [tabs[c] for c in pick], blocks, threads=os.cpu_count() or 8)
     e1, e2 = rel_err_rows(iq[pick], ref_iq), rel_err_rows(au[pick], ref_au)
     print(f"10k: iq rel {e1:.3e} audio rel {e2:.3e} over {len(pick)} sampled channels")
     assert e1 <= RTOL and e2 <= RTOL

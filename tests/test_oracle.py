@@ -68,6 +68,33 @@ def test_oracle_bit_exact_vs_reference_golden(oracle, name):
                 assert np.array_equal(_bits(r[k]), _bits(g[k][i])), f"{name} off={off} {k}: rel={rel_err(r[k], g[k][i])}"
 
 
+PAIR_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "pairs", "*.npz")))
+
+
+@pytest.mark.parametrize("name", PAIR_CASES)
+def test_oracle_bit_exact_vs_reference_on_the_pair_stress_fixtures(oracle, name):
+    """tests/golden/pairs: conjugate channel pairs under a carrier of up to 0.99 of full scale over a floor down to 0.01
+    (the reference's decimated IQ and audio): the restatement reproduces the portable build bit for bit there too."""
+    g = load_golden(name, "pairs")
+    ch, blocks = regen_blocks(g)
+    for i, off in enumerate(int(o) for o in g["offsets"]):
+        r = _run_chain(oracle, ch, g["tables"][i] if off != 0 else None, blocks)
+        for k in ("iq", "audio_lf", "out_lens"):
+            assert np.array_equal(_bits(r[k]), _bits(g[k][i])), f"{name} off={off} {k}"
+
+
+def test_the_reference_builds_disagree_by_more_than_the_tolerance_over_a_quiet_floor():
+    """Scale of the problem, second half: under a strong carrier every weak channel's error floor is set by the carrier, in the
+    reference itself -- its AVX2 (Release) and portable builds are 2e-5 to 5e-5 apart at a noise floor of 0.01 and within 1e-5
+    at 0.25.  A path that sums in any order but the portable build's cannot hold 1e-5 against it there (tests/test_gpu_pairs_stress.py)."""
+    import json
+    s = json.load(open(os.path.join(GOLD, "pairs", "SUMMARY.json")))
+    assert len(s) == len(PAIR_CASES) == 24
+    quiet = [v["avx2_max_rel_dev"] for k, v in s.items() if k.endswith("_n010")]
+    loud = [v["avx2_max_rel_dev"] for k, v in s.items() if k.endswith("_n250")]
+    assert min(quiet) > 1.5e-5 and max(loud) < 5e-6
+
+
 def test_reference_builds_agree_within_tolerance():
     """Scale of the problem: the reference's AVX2 and portable builds differ by < 1e-5 (but not 0)."""
     import json
