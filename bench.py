@@ -55,8 +55,6 @@ def parse_args(argv=None):
     ap.add_argument("--matrix", type=int, default=0, help="tuning.matrix_pipe: 0 auto, 1 vector kernels only, 2 require k_stage12m (mixer + stage 1 on the f32 matrix pipe)")
     ap.add_argument("--mgs", type=int, default=0, help="tuning.m_slot_groups (k_stage12m workgroup shape), 0 auto")
     ap.add_argument("--mgt", type=int, default=0, help="tuning.m_seg_groups, 0 auto")
-    ap.add_argument("--bg-tail", type=int, default=0, help="tuning.bg_tail: 0 auto, 1 tail stages after the stage-1/2 kernel, 2 require k_tail_bg beside it")
-    ap.add_argument("--bg-wgs", type=int, default=0, help="tuning.bg_wgs: workgroups of k_tail_bg, 0 = one per CU")
     ap.add_argument("--tail-tile", type=int, default=0, help="tuning.tail_tile (final outputs per workgroup of the separate tail kernel), 0 auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
@@ -492,9 +490,9 @@ def main():
         ring = torch.from_numpy(host).cuda()
 
     tuning = None
-    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile or args.bg_tail or args.bg_wgs:
+    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile:
         tuning = {"fused_tail": args.fused, "pair_lanes": args.pair, "matrix_pipe": args.matrix, "m_slot_groups": args.mgs, "m_seg_groups": args.mgt,
-                  "tail_tile": args.tail_tile, "bg_tail": args.bg_tail, "bg_wgs": args.bg_wgs}
+                  "tail_tile": args.tail_tile}
     fused_seen = {}
     pair_seen = {}
     matrix_seen = {}
@@ -547,18 +545,6 @@ def main():
             extra[name] = {"value": len(o) * L * max(10, args.steps) / dte / 1e6, "unit": "Mch-samples/s",
                            "ms_per_step": dte / max(10, args.steps) * 1e3, "realtime_factor": L * max(10, args.steps) / dte / ch.fs,
                            "kernel_ms_avg": {n: v[0] for n, v in ke.items()}, "fused_tail": fused_seen[len(o)]}
-
-    if world == 1 and not args.no_extra_configs and plan.name == "headline" and tuning is None and matrix_seen.get(n_ch):
-        # the same workload with the tail stages BESIDE the stage-1/2 kernel (tuning.bg_tail = 2, DESIGN 4.8: opt-in; 1 to 3.4 %
-        # over the boxes tried; needs the runtime to run two launches of the process at once)
-        try:
-            dtb, kb = run(offs, max(30, args.steps), args.warmup, tuning_override={"bg_tail": 2})
-            nb_steps = max(30, args.steps)
-            extra["the workload with tuning.bg_tail = 2 (tail stages beside the stage-1/2 kernel, opt-in)"] = {
-                "value": n_ch * L * nb_steps / dtb / 1e6, "unit": "Mch-samples/s", "ms_per_step": dtb / nb_steps * 1e3,
-                "realtime_factor": L * nb_steps / dtb / ch.fs, "kernel_ms_avg": {n: v[0] for n, v in kb.items()}}
-        except sb.SdrxGpuError as e:
-            extra["the workload with tuning.bg_tail = 2 (tail stages beside the stage-1/2 kernel, opt-in)"] = {"refused": str(e)}
 
     if world == 1 and not args.no_extra_configs and plan.name == "headline":
         # BASELINE configs[4], one GPU's share: 2 independent 10 MS/s streams x 1024 channels, each stream's block

@@ -105,14 +105,6 @@ typedef struct {
     uint32_t matrix_pipe;    /* mixer + stage 1 of the 10 MS/s chain on the f32 matrix pipe (k_stage12m: exact fp32
                                 fma chains in another summation order -- the one choice here whose outputs differ
                                 from the others', by rounding only): 0 = auto, 1 = never, 2 = require            */
-    uint32_t bg_tail;        /* banks on the matrix pipe: the tail stages run BESIDE the stage-1/2 kernel of the same block (one
-                                persistent low-footprint workgroup per CU takes the channels whose slot groups are complete;
-                                device and pinned entries; same outputs bit for bit): 0 = auto (off: 1 to 3.4 % of a 10 000-channel
-                                block depending on the box, paid for with a stage-1/2 kernel that runs 10 % longer beside it),
-                                1 = never, 2 = require.  Needs the two kernels to run at the same time: launches that the
-                                runtime puts on one hardware queue do not, the kernel then gives its channels back after
-                                50 ms, once, and switches itself off (bank_info.bg_tail == 2) */
-    uint32_t bg_wgs;         /*   workgroups of that background kernel, 0 = auto (one per CU) */
     uint32_t m_slot_groups;  /* k_stage12m workgroup = m_slot_groups x m_seg_groups tiles (waves) of 16 channel    */
     uint32_t m_seg_groups;   /*   pairs x 16 time segments: (2,2), (4,2) or (2,4); 0 = auto                        */
 } sdrxgpu_tuning;
@@ -184,9 +176,6 @@ typedef struct {
     uint32_t k12_bodies;       /*   bodies per lane */
     uint32_t matrix_pipe;      /* 1: mixer + stage 1 run on the f32 matrix pipe (k_stage12m) */
     uint32_t m_slots;          /*   its channel-pair slots (pairs + channels without partner + padding) */
-    uint32_t bg_tail;          /* 1: tail stages beside the stage-1/2 kernel (k_tail_bg / k_tail_bgs) on the device / pinned entries;
-                                  2: asked for, but switched off at run time: a wait for that kernel ran out once (the channels
-                                  concerned went back to the ordinary tail kernel; outputs unaffected) */
 } sdrxgpu_bank_info;
 
 /* Fill the AGC / LfAGC parameter blocks as sdrx configures them per channel

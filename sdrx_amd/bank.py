@@ -46,7 +46,7 @@ class AgcParams(C.Structure):
 class Tuning(C.Structure):
     """sdrxgpu_tuning: geometry / kernel-path overrides for tests and tuning runs (0 = automatic)."""
     _fields_ = [(k, C.c_uint32) for k in ("k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail", "host_parts", "pair_lanes",
-                                            "matrix_pipe", "bg_tail", "bg_wgs", "m_slot_groups", "m_seg_groups")]
+                                            "matrix_pipe", "m_slot_groups", "m_seg_groups")]
 
 
 FUSED_AUTO, FUSED_OFF, FUSED_REQUIRE = 0, 1, 2
@@ -72,7 +72,7 @@ class BankInfo(C.Structure):
                 ("history_len", C.c_uint32), ("samples_in", C.c_uint64), ("samples_out", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("fused_tail", C.c_uint32), ("pair_lanes", C.c_uint32),
                 ("k12_waves", C.c_uint32), ("k12_cpw", C.c_uint32), ("k12_bodies", C.c_uint32),
-                ("matrix_pipe", C.c_uint32), ("m_slots", C.c_uint32), ("bg_tail", C.c_uint32)]
+                ("matrix_pipe", C.c_uint32), ("m_slots", C.c_uint32)]
 
 
 _lib = None

@@ -335,7 +335,6 @@ struct Stage12Args {
     int c0;
     int n_y3;
     int seam_stride;        // float2 per channel of the seam buffer: [range][2][TA-1] (first / last TA-1 outputs of each range)
-    unsigned *done;         // k_stage12m beside k_tail_bg: [set] += 1 per finished item (after an agent-scope release); nullptr: off
 };
 
 // LDS tile geometry.  A wave's 64 lanes are CPW channels x SPW = 64/CPW time segments (lane =
@@ -1077,14 +1076,6 @@ struct TailArgs {
     // body-major storage of the new stage-2 outputs (see k_stage12): geometry of the launch that wrote them
     int y2b, seg_len, ph_len, spw_shift, spw, nb, P;       // seg_len = bps*Y2B, ph_len = nb*Y2B
     int y2b_shift;          // log2(y2b)
-    // overlapped tail (k_tail_bg beside k_stage12m, then this kernel for what is left): channels are taken from order[first ..],
-    // first = min(*next, n_units), instead of n_ch-1 downwards; nullptr: off
-    const int *order;
-    const unsigned *next;
-    int n_units;
-    int unit_shift;         //   units per channel = 1 << unit_shift (k_tail_bgs claims half channels); *next counts units
-    const unsigned *skipped; //   [n_units] == epoch: the background kernel claimed (part of) the channel in this call and gave it back
-    unsigned epoch;         //   (it had waited too long for the channel's rows); this kernel runs it
     int half_split;         // 1: written by k_stage12m -- a body's four outputs of a segment lie as two pairs, one in each of the
                             // body's two half-body rows: [time-wave][2 body + h][segment][2] (kernels_mfma.hpp); y2b is 4
     float rcp_seg_len, rcp_ph_len, rcp_y2b;
@@ -1252,7 +1243,7 @@ __device__ __forceinline__ int y2_group_index(const TailArgs &a, int j)
     return y2_storage_index(a, j);
 }
 
-// one (channel, tile) of k_tail_s: everything a workgroup of that kernel does (k_tail_bg walks channels with it)
+// one (channel, tile) of k_tail_s: everything a workgroup of that kernel does
 template <int MA, int TA, int MB, int TB>
 __device__ __forceinline__ void tail_s_unit(const TailArgs &a, const int ch, const int q, float2 *smem)
 {
@@ -1349,273 +1340,10 @@ __global__ __launch_bounds__(256) void k_tail_s(const TailArgs a)
     const int q = qq % a.n_tiles;
     const int chf = (qq / a.n_tiles) * 8 + xcd;
     if (chf >= a.n_ch) return;
-    int ch;
-    if (a.order) {                                         // what k_tail_bg left: units first .. n_units-1 of its list, from the
-        // last one down (the rows written last are the ones still cached); a channel of which only a part was claimed runs whole
-        const int first = (int)(min(*a.next, (unsigned)(a.n_units << a.unit_shift)) >> a.unit_shift);
-        const int j = a.n_units - 1 - chf;
-        if (j < first && __hip_atomic_load(a.skipped + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) return;
-        ch = a.order[j];
-    } else {
-        ch = a.n_ch - 1 - chf;
-        if (ch < a.ch_lo) return;
-    }
+    const int ch = a.n_ch - 1 - chf;
+    if (ch < a.ch_lo) return;
     tail_s_unit<MA, TA, MB, TB>(a, ch, q, smem);
 }
-
-// ------------------------------------------------------------------------------------------
-// k_tail_bg: the tail stages BESIDE the stage-1/2 kernel of the same block.  One persistent workgroup per CU (launched first, so
-// it has its place; 18 KB of LDS and ~50 VGPRs fit beside two workgroups of k_stage12m) takes channels from `order` (the slot
-// order k_stage12m works through) one after the other, waits until the channel's set of slot groups is complete -- k_stage12m
-// adds 1 to done[set] per finished item, after its stores have been released at agent scope --, and runs the channel's tiles
-// through tail_s_unit.  It stops claiming when `stop` is raised (by a one-thread kernel behind k_stage12m on its stream); what is
-// left then is k_tail_s's (TailArgs.order).  Measured beside a kernel of k_stage12m's shape (tools/ubench_corun.hip): one such
-// workgroup per CU streams 3.1 TB/s and costs the compute kernel 7.5 %; two per CU cost it 50 %.
-// ------------------------------------------------------------------------------------------
-struct BgArgs {
-    const unsigned *done;    // [sets] items of k_stage12m finished, ever (never reset)
-    unsigned target;         // ... a set of THIS block is complete at
-    unsigned *next;          // next unit to claim (reset to 0 per block)
-    const int *stop;         // != 0: claim nothing more
-    const int *order;        // [n_units] channel of unit i
-    const int *set_of;       // [n_units] its set
-    int n_units;
-    unsigned *skipped;       // [channels of `order`] = target: claimed in this call, but given back (see bg_claim)
-    int *disabled;           // != 0: a wait has run out once; the kernel claims nothing any more, in this call or a later one
-};
-
-#ifndef SDRX_BG_WAIT_TICKS
-#define SDRX_BG_WAIT_TICKS 5000000     // 50 ms of the 100 MHz clock (tests build the library with 0: every wait runs out)
-#endif
-// One claim of the background tail kernels, by thread 0 of the workgroup: the next unit of the list, once its set of slot groups is
-// complete (stop raised = the stage-1/2 kernel has ended: every set is).  The wait is bounded -- the stage-1/2 kernel may not be
-// running at all (both launches on one hardware queue, a GPU busy with somebody else's work): after 50 ms (5 M ticks of the
-// 100 MHz clock; the kernel itself takes 0.6 ms) the unit's channel goes back to k_tail_s (skipped[] = this call's target, which
-// k_tail_s compares with its epoch), the bank's background tail is switched off for good and the workgroup ends.  -1: nothing to do.
-__device__ __forceinline__ int bg_claim(const BgArgs &g, const int unit_shift)
-{
-    if (__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-        __hip_atomic_load(g.disabled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        return -1;
-    const int idx = (int)__hip_atomic_fetch_add(g.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (idx >= g.n_units) return -1;
-    const unsigned *d = g.done + g.set_of[idx >> unit_shift];
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int)(__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) {
-        if (__hip_atomic_load(g.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)SDRX_BG_WAIT_TICKS) {
-            __hip_atomic_store(g.skipped + (idx >> unit_shift), g.target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g.disabled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return -1;
-        }
-        __builtin_amdgcn_s_sleep(32);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 forgets what it held of the rows
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return idx;
-}
-
-template <int MA, int TA, int MB, int TB>
-__global__ __launch_bounds__(256) void k_tail_bg(const TailArgs a, const BgArgs g)
-{
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    __shared__ int s_idx;
-    const int tid = threadIdx.x;
-    // (few instructions, and every one of them stands between a memory round trip and the next: they go first -- measured +2 %
-    // channels done beside k_stage12m, which loses 1 % more)
-    __builtin_amdgcn_s_setprio(3);
-    for (;;) {
-        if (tid == 0) s_idx = bg_claim(g, 0);
-        __syncthreads();
-        const int idx = s_idx;
-        if (idx < 0) break;
-        const int ch = g.order[idx];
-        for (int q = 0; q < a.n_tiles; q++) {
-            tail_s_unit<MA, TA, MB, TB>(a, ch, q, smem);
-            __syncthreads();                               // the tile's LDS is free again (and s_idx may be rewritten after the last one)
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_tail_bgs: k_tail_bg as a STREAM.  tail_s_unit is a latency chain per tile (load 15 KB -> barrier -> stage A -> barrier ->
-// stage B) and re-reads a fifth of the scratch as tile halos; one workgroup per CU runs it at 1.3 TB/s.  Here a unit is half a
-// channel (256 final outputs): the workgroup walks the channel's row [hist | new] once, in chunks of one time-wave block (768
-// stage-2 outputs = 6 KB CONTIGUOUS in k_stage12m's half-body rows; NB of them), the next chunk in flight in registers while stage A runs
-// over the current one in LDS (time order restored by the LDS write; a 24-entry carry in front of the chunk), stage-A outputs
-// collected in LDS (1 342 entries), stage B over them at the end.  Same folded_fir_unrolled on the same operands as
-// tail_s_unit: the same bits.  For k_stage12m's layout with whole segments per lane (half_split, P == 1, 16 segments x 48
-// outputs per block: the host checks).
-// ------------------------------------------------------------------------------------------
-// s_waitcnt vmcnt(NPC * min(rem, K)): the wait for a register set behind which `rem` younger sets of NPC loads each were issued
-template <int K, int NPC>
-__device__ __forceinline__ void wait_loads_but(const int rem)
-{
-    if constexpr (K == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        if (rem >= K)
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(K * NPC) : "memory");
-        else
-            wait_loads_but<K - 1, NPC>(rem);
-    }
-}
-
-// one unit of the streamed tail: final outputs [NH h, NH h + NH) of channel ch (NH = 256: half a channel's block, 512: all of it);
-// every thread of the 256-thread workgroup calls it
-template <int MA, int TA, int MB, int TB, int NB, int NH, int DEPTH>
-__device__ __forceinline__ void tail_stream_unit(const TailArgs &a, const int ch, const int h, float2 *smem)
-{
-    constexpr int BLK = 768, BL = NB * BLK, CARRY = 24;    // chunk = NB time-wave blocks
-    constexpr int NWP = NB * 6;                            // wave-passes per chunk: a block = 3 groups of 8 half-body rows x 2 groups of 8 segments
-    constexpr int NPC = (NWP + 3) / 4 < 2 ? 2 : (NWP + 3) / 4;   // passes per wave (>= 2: the history chunk is up to 384 pieces)
-    static_assert(MA == 5 && TA == 21, "stage A of the 10 MS/s chain");
-    v2f *const ybuf = reinterpret_cast<v2f *>(smem);       // [CARRY | BL] stage-2 outputs in time order
-    v2f *const y3buf = ybuf + CARRY + BL;                   // [MB (NH - 1) + TB (+ slack)] stage-A outputs of the unit
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int n_blocks = (a.n_y2_new + BLK - 1) / BLK;
-    const int c_last = (n_blocks - 1) / NB;
-    const float2 *__restrict__ ynew = a.y2_new + (size_t)ch * a.y2_stride;
-    const float2 *__restrict__ hin = a.hist_in + (size_t)ch * a.hist;
-    // history for the next call = the last `hist` (<= 768) entries of the row: read while stage B runs, written after it -- at the
-    // top of the unit the read would be a memory round trip with nothing else in flight
-    float2 *__restrict__ hout = a.hist_out + (size_t)ch * a.hist;
-    auto hist_src = [&](int i) -> const float2 * {
-        const int p = a.n_y2_new + i;
-        return p < a.hist ? hin + p : ynew + y2_storage_index(a, p - a.hist);
-    };
-    const int s0 = h * NH;
-    const int nbt = min(a.n_b - s0, NH);
-    if (nbt <= 0) {
-        if (h == 0)
-            for (int i = tid; i < a.hist; i += 256) hout[i] = *hist_src(i);
-        return;
-    }
-    const int rA0 = a.pB0 + MB * s0;                       // first stage-A output of the unit
-    const int nrA = MB * (nbt - 1) + TB;
-    const int P0 = a.pA0 + MA * rA0;                       // first row entry it needs
-    // chunk c: row entries up to E(c); c = -1: the history (a.hist entries, contiguous), c >= 0: blocks NB c .. NB c + NB - 1 of the new part
-    auto chunk_end = [&](int c) { return c < 0 ? a.hist : a.hist + BL * (c + 1); };
-    int c = P0 < a.hist ? -1 : (P0 - a.hist) / BL;
-    // piece = 16 bytes = 2 entries; a block's piece (row, seg) = half-body row, segment lies (16 row + seg) * 16 bytes into the block
-    // and goes to entry 48 seg + 2 row of it.  A wave-pass moves 8 rows x 8 segments: 128 contiguous bytes per row from memory; lanes
-    // 8 k .. 8 k + 7 take the 8 rows of one segment, 128 contiguous bytes in LDS -- ds_write_b128 serves 8 contiguous lanes per cycle
-    // on 32 banks, and pieces 384 bytes apart (neighbouring segments in one group) would all land on the same four: 64 cycles per
-    // instruction instead of 13, measured as 0.13 ms of a 0.25 ms kernel.  Pass w = wave + 4 u of the chunk: block w / 6, row group
-    // (w % 6) >> 1, segment group w & 1.
-    // The history chunk (<= 384 entries) sits at the END of the chunk region, in order, pieces tid, tid + 256.
-    int goff[NPC], loff[NPC];                              // per pass: piece index in the chunk (16-byte units), first entry in ybuf; -1: none
-#pragma unroll
-    for (int u = 0; u < NPC; u++) {
-        const int w = wave + 4 * u;
-        const int kb = w / 6, ww = w - 6 * kb;
-        const int row = 8 * (ww >> 1) + (lane & 7), seg = 8 * (ww & 1) + (lane >> 3);
-        goff[u] = w < NWP ? kb * 384 + row * 16 + seg : -1;
-        loff[u] = CARRY + kb * BLK + seg * 48 + 2 * row;
-    }
-    v4f rq[DEPTH][NPC];                                    // DEPTH chunks in flight, in registers
-    // (one code path for the history chunk and the others -- index and address are selected, not the branch: two paths that
-    // fill different parts of a register set end up as an array in scratch memory)
-    const int np_h = a.hist / 2, base_h = CARRY + BL - a.hist;
-    auto fetch = [&](int cc, v4f (&r)[NPC]) __attribute__((always_inline)) {
-        // The loads are inline assembly: the compiler's own s_waitcnt placement takes the loop's register sets for one another and
-        // waits for ALL loads in flight before each stash (the chunks ahead are then no longer ahead).  stash waits for exactly its
-        // own set: loads return in order, and behind it min(DEPTH - 1, c_last - cc) younger sets of NPC loads each are out.
-        if (cc > c_last) return;
-        const v4f *src = cc < 0 ? reinterpret_cast<const v4f *>(hin) : reinterpret_cast<const v4f *>(ynew + (size_t)max(cc, 0) * BL);
-#pragma unroll
-        for (int u = 0; u < NPC; u++) {
-            const int ih = min(tid + 256 * u, np_h - 1);
-            const v4f *p = src + (cc < 0 ? ih : max(goff[u], 0));
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[u]) : "v"(p) : "memory");
-        }
-    };
-    auto stash = [&](int cc, v4f (&r)[NPC]) __attribute__((always_inline)) {
-        wait_loads_but<DEPTH - 1, NPC>(c_last - cc);
-#pragma unroll
-        for (int u = 0; u < NPC; u++) asm volatile("" : "+v"(r[u]));       // (nothing reads the set before the wait)
-#pragma unroll
-        for (int u = 0; u < NPC; u++) {
-            const bool ok = cc < 0 ? tid + 256 * u < np_h : goff[u] >= 0;
-            const int at = cc < 0 ? base_h + 2 * (tid + 256 * u) : loff[u];
-            if (ok) *reinterpret_cast<v4f *>(ybuf + at) = r[u];
-        }
-    };
-    int done_hi = rA0 - 1;                                 // stage-A outputs up to here are computed
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++) fetch(c + d, rq[d]);
-    auto chunk = [&](int cc, v4f (&cur)[NPC]) __attribute__((always_inline)) {
-        stash(cc, cur);
-        fetch(cc + DEPTH, cur);                            // the registers just emptied take the chunk DEPTH ahead
-        __syncthreads();
-        const int E = chunk_end(cc);
-        v4f keep = v4f{0.f, 0.f, 0.f, 0.f};
-        if (tid < CARRY / 2) keep = *reinterpret_cast<const v4f *>(ybuf + BL + 2 * tid);   // the chunk's last CARRY entries = the next one's carry
-        if (E - TA - a.pA0 >= 0) {
-            const int hi = min((E - TA - a.pA0) / MA, rA0 + nrA - 1);   // last output whose window ends inside the chunk
-#pragma unroll 1
-            for (int r = done_hi + 1 + tid; r <= hi; r += 256) {
-                const int e0 = a.pA0 + MA * r - (E - (CARRY + BL));       // buffer entry of the window's first sample
-                y3buf[r - rA0] = folded_fir_unrolled<TA>(ybuf + e0, a.hA);
-            }
-            done_hi = max(done_hi, hi);
-        }
-        __syncthreads();
-        if (tid < CARRY / 2) *reinterpret_cast<v4f *>(ybuf + 2 * tid) = keep;
-    };
-    for (bool more = true; more;) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            if (more && c <= c_last && done_hi < rA0 + nrA - 1) {
-                chunk(c, rq[d]);
-                c++;
-            } else {
-                more = false;
-            }
-        }
-    }
-    // (the fetches past the last chunk the unit needed are still in flight, into registers the compiler takes for free from here on)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    float2 hv[3];
-    if (h == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) hv[k] = *hist_src(min(tid + 256 * k, a.hist - 1));
-    }
-#pragma unroll 1
-    for (int o = tid; o < nbt; o += 256) {
-        const v2f r = folded_fir_unrolled<TB>(y3buf + MB * o, a.hB);
-        const float2 v = make_float2(r.x, r.y);
-        if (a.iq_out) a.iq_out[(size_t)ch * a.out_stride + s0 + o] = v;
-        if (a.iq_keep) a.iq_keep[(size_t)ch * a.keep_stride + s0 + o] = v;
-    }
-    if (h == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            if (tid + 256 * k < a.hist) hout[tid + 256 * k] = hv[k];
-    }
-}
-
-template <int MA, int TA, int MB, int TB, int NB, int DEPTH>
-// (launch bounds: 6 waves per SIMD as the register budget = 80 VGPRs: what two waves of k_stage12m's lean build, 216 each, leave)
-__global__ __launch_bounds__(256, 6) void k_tail_bgs(const TailArgs a, const BgArgs g)
-{
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    __shared__ int s_idx;
-    const int tid = threadIdx.x;
-    __builtin_amdgcn_s_setprio(3);
-    for (;;) {
-        if (tid == 0) s_idx = bg_claim(g, 1);
-        __syncthreads();
-        const int idx = s_idx;
-        if (idx < 0) break;
-        tail_stream_unit<MA, TA, MB, TB, NB, 256, DEPTH>(a, g.order[idx >> 1], idx & 1, smem);
-        __syncthreads();
-    }
-}
-
-__global__ void k_bg_set(unsigned *next, int *stop, const int reset) { if (reset) *next = 0u; *stop = reset ? 0 : 1; }
 
 // ------------------------------------------------------------------------------------------
 // k_tail4: what follows a k_stage12 with fused stage 3.  One workgroup per channel:

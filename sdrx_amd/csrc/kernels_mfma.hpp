@@ -25,7 +25,7 @@
 // (C/D row 4*(lane>>4)+r = slot 2*(lane>>4) + (r>>1), part r&1; column = segment lane&15).  A workgroup = GS slot groups x GT segment groups = GS*GT waves that
 // share GT*16 input rows and GS*16 translator rows in LDS (LDS-DMA, two buffers of half a body = 50 samples + 12 of
 // history each).  Segments, bodies (100 samples = 20 stage-1 outputs = 4 stage-2 outputs), warm-up and the body-major
-// stage-2 scratch are k_stage12's, so the tail kernels do not know which kernel ran.
+// stage-2 scratch are k_stage12's but for the order inside a body (half-body rows: TailArgs.half_split tells the tail kernels).
 // Stage 2 (19 taps, /5) runs in TRANSPOSED form: a stage-1 output is multiplied into the (at most four) stage-2 outputs
 // whose windows hold it, so a lane carries 4 accumulators per value instead of a 14-deep delay line -- what makes 8
 // channel-segments per lane fit the register file.  Each output is still one fma chain over its 19 inputs in order
@@ -55,17 +55,15 @@ struct Stage12mTaps {
 };
 
 // A wave's memory instructions -- LDS-DMA for the next half-body, stores of the previous one's outputs -- go out a piece per phase
-// instead of in a burst behind the barrier (-5 % on the launch).  LEAN = false (the ordinary launch): also, the first six phases of
-// a lane's warm-up body (nobody's input) are skipped (-1.5 %): a second path through the half-body, 256 VGPRs and a few spills.
-// LEAN = true: not that, and the DMA row offsets as scalars; 212 VGPRs, what the launch beside k_tail_bg / k_tail_bgs may have (two of these waves and one of theirs
-// per SIMD: 2 x 216 + 80).
-template <int GS, int GT, bool LEAN>
+// instead of in a burst behind the barrier (-5 % on the launch).  The first six phases of a lane's warm-up body (nobody's input)
+// are skipped (-1.5 %): a second path through the half-body, 256 VGPRs and a few spills (none touched inside the loop).
+template <int GS, int GT>
 __global__ __launch_bounds__(64 * GS * GT, 2)
 void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tables, float2 *__restrict__ y2_out,
                 const Stage12Args a, const PairArgs pa, const Stage12mTaps taps)
 {
     using G = TileGeomM<GS, GT>;
-    constexpr bool TRIM = !LEAN;
+    constexpr bool TRIM = true;
     constexpr int SB = 100, Y2B = 4, SPW = 16;
     constexpr int RB = G::row_bytes;
     extern __shared__ __attribute__((aligned(16))) char lds_m[];
@@ -89,16 +87,7 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     const int gq = wtm / a.P, p = wtm - gq * a.P;
     const int bps = a.nb * a.P;
     const int g_first = gq * GT;                            // first segment group of the workgroup
-    // (beside k_tail_bg every item of a set reports, also one that has nothing to do)
-    // (the item's stores are write-through then -- sc1, store_staged -- and every wave has waited for its own before the
-    // barrier in front of this: no release fence, which would write back the whole XCD's dirty lines once per item)
-    auto report = [&]() {
-        if (tid == 0) __hip_atomic_fetch_add(a.done + cgm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    if ((g_first * SPW * bps + a.nb * p) * Y2B >= a.n_y2_new) {
-        if (a.done) report();
-        continue;
-    }
+    if ((g_first * SPW * bps + a.nb * p) * Y2B >= a.n_y2_new) continue;
 
     // ---- what this lane stores: slots 4*hi + r of the wave's group, both channels of each.  A place without channel
     // (empty slot, no partner) stores into the spare row behind the last channel's: no branch around any store ----
@@ -122,11 +111,8 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     const int rsel = lane < G::pieces_a ? 0 : 1;
     // (rows of segments past the last segment group that holds data re-read its last segment: inside the ring)
     const int seg_max = ((a.n_y2_new + Y2B - 1) / Y2B + SPW * bps - 1) / (SPW * bps) * SPW - 1;
-    // per pair and lane: the byte offset from the pair's wave-uniform base.  The ordinary build keeps it in a register per pair;
-    // the lean build keeps the two rows' offsets of a pair as scalars and lets the lane add its piece at the DMA (8 registers less
-    // -- what brings it under the 216 it may have --, 1.4 % more time)
-    uint32_t dma_off[LEAN ? 1 : G::pairs_per_wave];
-    uint32_t dma_row[LEAN ? G::pairs_per_wave : 1][2];
+    // per pair and lane: the byte offset from the pair's wave-uniform base, in a register per pair
+    uint32_t dma_off[G::pairs_per_wave];
     int dma_is_t[G::pairs_per_wave];
     const uint32_t piece16 = (uint32_t)piece * 16u;
 #pragma unroll
@@ -143,17 +129,9 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
             if (c < 0) c = 0;                               // an empty slot works on channel 0's table and stores nothing
             return (uint32_t)((size_t)c * a.tbl_stride * 8);
         };
-        if constexpr (LEAN) {
-            dma_row[i][0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_off(2 * k));
-            dma_row[i][1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_off(2 * k + 1));
-        } else {
-            dma_off[i] = row_off(2 * k + rsel) + piece16;
-        }
+        dma_off[i] = row_off(2 * k + rsel) + piece16;
     }
-    auto lane_off = [&](int i) -> uint32_t {
-        if constexpr (LEAN) return (rsel ? dma_row[i][1] : dma_row[i][0]) + piece16;
-        else return dma_off[i];
-    };
+    auto lane_off = [&](int i) -> uint32_t { return dma_off[i]; };
     int tph = a.tphase0 + p * a.nb * SB - G::HALO;          // translator index of the first entry of half-body 0's rows
     tph %= a.N;
     if (tph < 0) tph += a.N;
@@ -253,18 +231,12 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     // Scratch layout: k_stage12's body-major rows with HALF-bodies as the bodies -- [time-wave][half-body][segment][2] --, so that
     // the 16 lanes of a channel write 256 contiguous bytes per store and no 32-byte sector is written in two goes (with whole
     // bodies of four outputs per segment the two halves of every sector came ten phases apart: 2.0 GB of HBM writes per
-    // launch for 1.07 GB of outputs).  The tail kernels are told so (y2b = 2, twice the bodies).
+    // launch for 1.07 GB of outputs).  The tail kernels are told so: TailArgs.half_split (y2b stays 4).
     v4f stage[8];                                           // per channel: (re, im) of the half-body's first output, of its second
     const uint32_t ylane = (uint32_t)a.y2_hist + ((uint32_t)wt * (2 * a.nb) * SPW + lo) * 2;
     auto store_staged_part = [&](int body, int h, int i0, int i1) {     // channels i0 .. i1 - 1 of the lane's eight
         if (body < 0 || !seg_live) return;
         const uint32_t at = ylane + (uint32_t)(2 * body + h) * SPW * 2;
-        if (a.done) {       // beside k_tail_bg: write-through, so that a counter behind vmcnt(0) + barrier publishes the rows (MI355X_MICROARCH.md, valid forms)
-#pragma unroll
-            for (int i = i0; i < i1; i++)
-                asm volatile("global_store_dwordx4 %0, %1, %2 sc1" : : "v"((yrow[i] + at) * 8u), "v"(stage[i]), "s"(y2_out) : "memory");
-            return;
-        }
         // (scalar base + 32-bit byte offset per lane: one address register per store -- these stores sit between the phases now,
         // where the register file is full; the host keeps the scratch below 4 GB)
 #pragma unroll
@@ -399,11 +371,6 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     if (item + (int)gridDim.x < n_items) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-    }
-    if (a.done) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's stores have left it ...
-        __syncthreads();
-        report();                                               // ... then one lane releases them and counts the item
     }
     // (the next item's first rows go to buffer 0, which every wave left before the barrier of the last half-body)
     }

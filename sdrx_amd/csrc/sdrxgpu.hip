@@ -297,50 +297,39 @@ struct K12mLaunch {
     int GS, GT;
 };
 
-#ifndef SDRX_BGS_DEPTH
-#define SDRX_BGS_DEPTH 1    // chunks of k_tail_bgs in flight per workgroup (12 registers per thread each; 2 measured the same, 3 worse)
-#endif
-#ifndef SDRX_BGS_NB
-#define SDRX_BGS_NB 2       // time-wave blocks per chunk of k_tail_bgs (its LDS: 24 + 768 NB + 1 342 entries)
-#endif
-static size_t bgs_lds_bytes() { return (size_t)(24 + 768 * SDRX_BGS_NB + 5 * 255 + 67 + 24) * sizeof(float2); }
-
 static bool k12m_geometry_compiled(int GS, int GT) { return (GS == 2 && GT == 2) || (GS == 4 && GT == 2) || (GS == 2 && GT == 4); }
 static size_t k12m_lds_bytes(int GS, int GT) { return 2 * (size_t)(16 * GS + 16 * GT) * 528; }
 
-template <int GS, int GT, bool LEAN>
+template <int GS, int GT>
 static hipError_t launch_k12m_one(const K12mLaunch &M, const Stage12mTaps &taps, hipStream_t s)
 {
     using TG = TileGeomM<GS, GT>;
     static_assert(2 * TG::buf_bytes <= 160 * 1024, "two tile buffers must fit the LDS");
-    hipLaunchKernelGGL((k_stage12m<GS, GT, LEAN>), dim3(M.L.grid), dim3(64 * GS * GT), 2 * TG::buf_bytes, s,
+    hipLaunchKernelGGL((k_stage12m<GS, GT>), dim3(M.L.grid), dim3(64 * GS * GT), 2 * TG::buf_bytes, s,
                        M.L.x, M.L.tables, M.L.y2, M.L.args, M.pa, taps);
     return hipGetLastError();
 }
 
-// `lean`: the 212-VGPR build (whole warm-up body, scalar DMA offsets) that leaves a SIMD room for a wave of k_tail_bg beside two of its own
-static hipError_t launch_k12m(const K12mLaunch &M, bool lean, hipStream_t s)
+static hipError_t launch_k12m(const K12mLaunch &M, hipStream_t s)
 {
     Stage12mTaps taps{};
     for (int i = 0; i < 17; i++) taps.h1[i] = M.L.h1[i < 9 ? i : 16 - i];     // (the reference reads h[0 .. half] only, msd.hpp:309-331)
     for (int i = 0; i < 10; i++) taps.h2[i] = M.L.h2[i];
-    if (M.GS == 2 && M.GT == 2) return lean ? launch_k12m_one<2, 2, true>(M, taps, s) : launch_k12m_one<2, 2, false>(M, taps, s);
-    if (M.GS == 4 && M.GT == 2) return lean ? launch_k12m_one<4, 2, true>(M, taps, s) : launch_k12m_one<4, 2, false>(M, taps, s);
-    if (M.GS == 2 && M.GT == 4) return lean ? launch_k12m_one<2, 4, true>(M, taps, s) : launch_k12m_one<2, 4, false>(M, taps, s);
+    if (M.GS == 2 && M.GT == 2) return launch_k12m_one<2, 2>(M, taps, s);
+    if (M.GS == 4 && M.GT == 2) return launch_k12m_one<4, 2>(M, taps, s);
+    if (M.GS == 2 && M.GT == 4) return launch_k12m_one<2, 4>(M, taps, s);
     return hipErrorInvalidValue;
 }
 
 static hipError_t k12m_set_attributes(int GS, int GT)
 {
     const int n = (int)k12m_lds_bytes(GS, GT);
-    const void *f[2] = {nullptr, nullptr};
-    if (GS == 2 && GT == 2) { f[0] = reinterpret_cast<const void *>(&k_stage12m<2, 2, true>); f[1] = reinterpret_cast<const void *>(&k_stage12m<2, 2, false>); }
-    if (GS == 4 && GT == 2) { f[0] = reinterpret_cast<const void *>(&k_stage12m<4, 2, true>); f[1] = reinterpret_cast<const void *>(&k_stage12m<4, 2, false>); }
-    if (GS == 2 && GT == 4) { f[0] = reinterpret_cast<const void *>(&k_stage12m<2, 4, true>); f[1] = reinterpret_cast<const void *>(&k_stage12m<2, 4, false>); }
-    if (!f[0]) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(f[0], hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    if (e == hipSuccess) e = hipFuncSetAttribute(f[1], hipFuncAttributeMaxDynamicSharedMemorySize, n);
-    return e;
+    const void *f = nullptr;
+    if (GS == 2 && GT == 2) f = reinterpret_cast<const void *>(&k_stage12m<2, 2>);
+    if (GS == 4 && GT == 2) f = reinterpret_cast<const void *>(&k_stage12m<4, 2>);
+    if (GS == 2 && GT == 4) f = reinterpret_cast<const void *>(&k_stage12m<2, 4>);
+    if (!f) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, n);
 }
 
 struct K12Entry {
@@ -473,16 +462,6 @@ struct sdrxgpu_bank {
     int2 *d_slots_m = nullptr, *d_slots_mp = nullptr;  // partners from the whole bank / from inside each host part
     int n_slots_m = 0, n_slots_mp = 0, n_pairs_m = 0;
     std::vector<int> part_gm;                         // set boundaries of the host parts
-    // tail stages beside the stage-1/2 kernel of the same block (k_tail_bg, kernels.hpp): whole-bank launches of the device /
-    // pinned entries.  order / set_of: the channels in the order k_stage12m's slot list works through, and their sets
-    bool bg_tail = false;
-    hipStream_t stream_bg = nullptr;
-    hipEvent_t ev_bg_go = nullptr, ev_bg_done = nullptr;
-    unsigned *d_bg_done = nullptr, *d_bg_next = nullptr, *d_bg_skipped = nullptr;
-    int *d_bg_disabled = nullptr;
-    int *d_bg_stop = nullptr, *d_bg_order = nullptr, *d_bg_set_of = nullptr;
-    unsigned bg_target = 0;                           // items per set k_stage12m has reported when the current block is complete
-    int bg_cus = 256;
     bool pair = false, want_pair = false;
     int2 *d_slots = nullptr;
     unsigned char *d_group_conj = nullptr;            // per slot group: conjugate partners (one translator row per slot) or any two channels
@@ -518,11 +497,41 @@ static int dev_alloc(sdrxgpu_bank *b, void **p, size_t bytes)
     return SDRXGPU_OK;
 }
 
+// Host -> device upload of set-up data (tables, slot lists, taps).  On the BANK'S OWN stream, and complete on return (the source
+// is a temporary): a bank enqueues nothing anywhere else, so waiting for its stream is waiting for all of its work.  Rounds 2-3
+// used blocking hipMemcpy here, i.e. the NULL stream, which the bank's non-blocking stream neither orders with nor waits for:
+// the runtime keeps the last command of a queue alive -- and with it a reference to the command's destination buffer -- until that
+// queue is used or synchronised again, so hipFree of the tables at destroy dropped a reference and freed nothing (DESIGN.md 7;
+// tools/leak_probe.py reproduces it with lab builds: -DSDRX_LAB_UPLOAD=1 leaks, with -DSDRX_LAB_CREATE_SYNC=1 or =2 it does not).
+#ifndef SDRX_LAB_UPLOAD
+#define SDRX_LAB_UPLOAD 0
+#endif
+#ifndef SDRX_LAB_CREATE_SYNC
+#define SDRX_LAB_CREATE_SYNC 0
+#endif
+static hipError_t upload(sdrxgpu_bank *b, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return hipSuccess;
+#if SDRX_LAB_UPLOAD == 1
+    (void)b;
+    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+#else
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    return e;
+#endif
+}
+
 static thread_local sdrxgpu_bank *g_creating = nullptr;   // bank under construction (freed if an exception ends bank_create)
 
-static void free_bank(sdrxgpu_bank *b)
+// (returns how many hipFree calls failed: sdrxgpu_bank_destroy reports them instead of ignoring them)
+static int free_bank(sdrxgpu_bank *b)
 {
-    if (!b) return;
+    if (!b) return 0;
+    int n_bad = 0;
+    auto fr = [&](void *p) {
+        if (p && hipFree(p) != hipSuccess) n_bad++;
+    };
     if (g_creating == b) g_creating = nullptr;
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (ProfSpan &s : b->prof_pending) {
@@ -530,11 +539,11 @@ static void free_bank(sdrxgpu_bank *b)
         (void)hipEventDestroy(s.b);
     }
     for (hipEvent_t e : b->pool) (void)hipEventDestroy(e);
-    (void)hipFree(b->d_xr[0]);
-    (void)hipFree(b->d_xr[1]);
-    (void)hipFree(b->d_tables);
-    (void)hipFree(b->d_y2);
-    (void)hipFree(b->d_y2b);
+    fr(b->d_xr[0]);
+    fr(b->d_xr[1]);
+    fr(b->d_tables);
+    fr(b->d_y2);
+    fr(b->d_y2b);
     if (b->stream2) {
         (void)hipStreamSynchronize(b->stream2);
         (void)hipStreamDestroy(b->stream2);
@@ -549,46 +558,37 @@ static void free_bank(sdrxgpu_bank *b)
         if (e) (void)hipEventDestroy(e);
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
-    (void)hipFree(b->d_hist[0]);
-    (void)hipFree(b->d_hist[1]);
-    (void)hipFree(b->d_y3);
-    (void)hipFree(b->d_hist2);
-    (void)hipFree(b->d_hist3);
-    (void)hipFree(b->d_seam);
-    (void)hipFree(b->d_slots);
-    (void)hipFree(b->d_slots_m);
-    (void)hipFree(b->d_bg_done);
-    (void)hipFree(b->d_bg_skipped);
-    (void)hipFree(b->d_bg_disabled);
-    (void)hipFree(b->d_bg_next);
-    (void)hipFree(b->d_bg_stop);
-    (void)hipFree(b->d_bg_order);
-    (void)hipFree(b->d_bg_set_of);
-    if (b->stream_bg) (void)hipStreamDestroy(b->stream_bg);
-    if (b->ev_bg_go) (void)hipEventDestroy(b->ev_bg_go);
-    if (b->ev_bg_done) (void)hipEventDestroy(b->ev_bg_done);
-    (void)hipFree(b->d_group_conj);
-    (void)hipFree(b->d_keep);
-    (void)hipFree(b->d_audio_keep);
-    (void)hipFree(b->d_state);
-    (void)hipFree(b->d_sql);
-    (void)hipFree(b->d_snr);
-    (void)hipFree(b->d_sql_level);
-    (void)hipFree(b->d_sq_tabs);
-    (void)hipFree(b->d_tw);
-    (void)hipFree(b->d_fir_taps);
-    (void)hipFree(b->d_fir_hist);
-    (void)hipFree(b->d_fm);
-    (void)hipFree(b->d_fm_prev);
-    (void)hipFree(b->d_pan_w);
-    (void)hipFree(b->d_mix_partial);
-    (void)hipFree(b->d_mix);
-    (void)hipFree(b->d_mix_f32);
-    (void)hipFree(b->d_mix_s16);
-    (void)hipFree(b->d_mix_taps);
-    (void)hipFree(b->d_mix_hist);
+    fr(b->d_hist[0]);
+    fr(b->d_hist[1]);
+    fr(b->d_y3);
+    fr(b->d_hist2);
+    fr(b->d_hist3);
+    fr(b->d_seam);
+    fr(b->d_slots);
+    fr(b->d_slots_m);
+    fr(b->d_group_conj);
+    fr(b->d_keep);
+    fr(b->d_audio_keep);
+    fr(b->d_state);
+    fr(b->d_sql);
+    fr(b->d_snr);
+    fr(b->d_sql_level);
+    fr(b->d_sq_tabs);
+    fr(b->d_tw);
+    fr(b->d_fir_taps);
+    fr(b->d_fir_hist);
+    fr(b->d_fm);
+    fr(b->d_fm_prev);
+    fr(b->d_pan_w);
+    fr(b->d_mix_partial);
+    fr(b->d_mix);
+    fr(b->d_mix_f32);
+    fr(b->d_mix_s16);
+    fr(b->d_mix_taps);
+    fr(b->d_mix_hist);
     if (b->owns_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
+    return n_bad;
 }
 
 static int init_state(sdrxgpu_bank *b)
@@ -697,6 +697,17 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     if (!b) return fail(SDRXGPU_ERR_NO_MEM, "bank_create: host allocation failed");
     g_creating = b;
     b->device = dev;
+    // the bank's stream first: every upload below goes through it (upload())
+    if (cfg->stream) {
+        b->stream = (hipStream_t)cfg->stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        b->owns_stream = true;
+    }
     b->n_ch = cfg->n_channels;
     b->n_stages = cfg->n_stages;
     b->flags = cfg->flags;
@@ -759,6 +770,16 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     b->spacing = (int)((long long)b->Neff / gcd_ll(b->Neff, b->SB) * b->SB);
     b->bps = b->spacing / b->SB;
     b->tbl_stride = b->Neff + b->SB;
+    // k_stage12m addresses translator rows by 32-bit byte offsets from the table base (LDS-DMA source = scalar base + lane offset)
+    if (b->mfma && (uint64_t)b->n_ch * (uint64_t)b->tbl_stride * sizeof(float2) >= (1ull << 32)) {
+        if (tune0.matrix_pipe == 2) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = 2, but %u tables of %d entries exceed k_stage12m's 32-bit row offsets",
+                        b->n_ch, b->tbl_stride);
+        }
+        b->mfma = false;                                        // automatic choice: the vector kernels
+        b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
+    }
 
     // tail-stage history: stage-2 outputs the remaining stages still need from earlier calls
     {
@@ -1050,8 +1071,8 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             free_bank(b);
             return rc2;
         }
-        hipError_t e = hipMemcpy(b->d_slots, slots.data(), slots.size() * sizeof(int2), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(b->d_group_conj, group_conj.data(), group_conj.size(), hipMemcpyHostToDevice);
+        hipError_t e = upload(b, b->d_slots, slots.data(), slots.size() * sizeof(int2));
+        if (e == hipSuccess) e = upload(b, b->d_group_conj, group_conj.data(), group_conj.size());
         if (e == hipSuccess) e = k12p_set_attributes();
         if (e != hipSuccess) {
             free_bank(b);
@@ -1118,94 +1139,13 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             return rc2;
         }
         b->d_slots_mp = b->d_slots_m + slots_all.size();
-        hipError_t e = hipMemcpy(b->d_slots_m, slots_all.data(), slots_all.size() * sizeof(int2), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(b->d_slots_mp, slots_parts.data(), slots_parts.size() * sizeof(int2), hipMemcpyHostToDevice);
+        hipError_t e = upload(b, b->d_slots_m, slots_all.data(), slots_all.size() * sizeof(int2));
+        if (e == hipSuccess) e = upload(b, b->d_slots_mp, slots_parts.data(), slots_parts.size() * sizeof(int2));
         if (e == hipSuccess) e = k12m_set_attributes(b->mGS, b->mGT);
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "k_stage12m set-up failed: %s", hipGetErrorString(e));
         }
-        // Tail stages beside the stage-1/2 kernel (k_tail_bg): the 10 MS/s chain's compiled tail, not pipelined
-        {
-            const bool can = cfg->n_stages == 4 && b->m[2] == 5 && b->ntaps[2] == 21 && b->m[3] == 5 && b->ntaps[3] == 67 && !b->pipelined &&
-                             !b->tail_generic;
-            if (tune.bg_tail > 2 || (tune.bg_tail == 2 && !can)) {
-                free_bank(b);
-                return fail(tune.bg_tail > 2 ? SDRXGPU_ERR_INVALID_ARG : SDRXGPU_ERR_UNSUPPORTED,
-                            "bank_create: tuning.bg_tail %u (0..2; 2 needs the 10 MS/s chain's tail (5,21)(5,67), no pipelining, no generic tail)", tune.bg_tail);
-            }
-            // (not automatic: 0.842-0.863 against 0.867-0.872 ms per 10 000-channel block, 1 to 3.4 % depending on the box --
-            // k_tail_bgs gets through 40 % of the tail while k_stage12m runs, which takes 10 % longer beside it; and the bench's
-            // roofline figure is that kernel's duration)
-            b->bg_tail = can && tune.bg_tail == 2;
-        }
-        if (b->bg_tail) {
-            std::vector<int> order, set_of;
-            for (size_t i = 0; i < slots_all.size(); i++) {
-                if (slots_all[i].x >= 0) { order.push_back(slots_all[i].x); set_of.push_back((int)(i / set)); }
-                if (slots_all[i].x >= 0 && slots_all[i].y >= 0) { order.push_back(slots_all[i].y); set_of.push_back((int)(i / set)); }
-            }
-            const size_t n_sets = slots_all.size() / set + 8;
-            if (order.size() != b->n_ch) {
-                free_bank(b);
-                return fail(SDRXGPU_ERR_HIP, "internal: %zu channels in the slot list of a bank of %u", order.size(), b->n_ch);
-            }
-            if ((rc2 = dev_alloc(b, (void **)&b->d_bg_done, n_sets * sizeof(unsigned))) ||
-                (rc2 = dev_alloc(b, (void **)&b->d_bg_next, 64)) || (rc2 = dev_alloc(b, (void **)&b->d_bg_stop, 64)) ||
-                (rc2 = dev_alloc(b, (void **)&b->d_bg_skipped, order.size() * sizeof(unsigned))) || (rc2 = dev_alloc(b, (void **)&b->d_bg_disabled, 64)) ||
-                (rc2 = dev_alloc(b, (void **)&b->d_bg_order, order.size() * sizeof(int))) ||
-                (rc2 = dev_alloc(b, (void **)&b->d_bg_set_of, set_of.size() * sizeof(int)))) {
-                free_bank(b);
-                return rc2;
-            }
-            e = hipMemset(b->d_bg_done, 0, n_sets * sizeof(unsigned));
-            if (e == hipSuccess) e = hipMemset(b->d_bg_next, 0, 64);
-            if (e == hipSuccess) e = hipMemset(b->d_bg_stop, 0, 64);
-            if (e == hipSuccess) e = hipMemset(b->d_bg_skipped, 0, order.size() * sizeof(unsigned));     // (a call's target is never 0)
-            if (e == hipSuccess) e = hipMemset(b->d_bg_disabled, 0, 64);
-            if (e == hipSuccess) e = hipMemcpy(b->d_bg_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMemcpy(b->d_bg_set_of, set_of.data(), set_of.size() * sizeof(int), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream_bg, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_bg_go, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_bg_done, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_bg<5, 21, 5, 67>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->tail_lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_bgs<5, 21, 5, 67, SDRX_BGS_NB, SDRX_BGS_DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bgs_lds_bytes());
-            if (e != hipSuccess) {
-                free_bank(b);
-                return fail(SDRXGPU_ERR_HIP, "k_tail_bg set-up failed: %s", hipGetErrorString(e));
-            }
-            // The scheme rests on two waves of k_stage12m's lean build and one of the background kernel sharing a SIMD's 512
-            // registers (granules of 8): with a build in which they do not, the background workgroup would take the place of a
-            // k_stage12m workgroup on every CU -- measured 0.93 against 0.86 ms per block.  Checked, not assumed.
-            {
-                hipFuncAttributes am{}, ab{}, ac{};
-                const void *fm = b->mGS == 2 && b->mGT == 2 ? reinterpret_cast<const void *>(&k_stage12m<2, 2, true>)
-                               : b->mGS == 4 ? reinterpret_cast<const void *>(&k_stage12m<4, 2, true>) : reinterpret_cast<const void *>(&k_stage12m<2, 4, true>);
-                e = hipFuncGetAttributes(&am, fm);
-                if (e == hipSuccess) e = hipFuncGetAttributes(&ab, reinterpret_cast<const void *>(&k_tail_bgs<5, 21, 5, 67, SDRX_BGS_NB, SDRX_BGS_DEPTH>));
-                if (e == hipSuccess) e = hipFuncGetAttributes(&ac, reinterpret_cast<const void *>(&k_tail_bg<5, 21, 5, 67>));
-                const int gm = (am.numRegs + 7) / 8 * 8, gb = (std::max(ab.numRegs, ac.numRegs) + 7) / 8 * 8;
-                const int waves_m = 2;                                      // waves of k_stage12m per SIMD (two workgroups of 4 waves or one of 8 per CU)
-                if (e != hipSuccess || waves_m * gm + gb > 512) {
-                    free_bank(b);
-                    return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.bg_tail = 2, but this build's kernels do not share a SIMD (%d x %d + %d registers)",
-                                waves_m, gm, gb);
-                }
-            }
-            b->bg_cus = tune.bg_wgs ? (int)std::min<uint32_t>(tune.bg_wgs, 4096u) : (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
-            b->bg_target = 0;
-        }
-    }
-
-    if (cfg->stream) {
-        b->stream = (hipStream_t)cfg->stream;
-    } else {
-        hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            free_bank(b);
-            return fail(SDRXGPU_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
-        }
-        b->owns_stream = true;
     }
 
     // ---- device memory ----
@@ -1260,7 +1200,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 }
             }
         }
-        hipError_t e = hipMemcpy(b->d_tables, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice);
+        hipError_t e = upload(b, b->d_tables, host.data(), host.size() * sizeof(float2));
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "table upload failed: %s", hipGetErrorString(e));
@@ -1308,9 +1248,9 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             free_bank(b);
             return rc;
         }
-        hipError_t e = hipMemcpy(b->d_sql_level, cfg->sql_level, (size_t)b->n_ch * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(b->d_sq_tabs, tabs.data(), tabs.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(b->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
+        hipError_t e = upload(b, b->d_sql_level, cfg->sql_level, (size_t)b->n_ch * sizeof(float));
+        if (e == hipSuccess) e = upload(b, b->d_sq_tabs, tabs.data(), tabs.size() * sizeof(float));
+        if (e == hipSuccess) e = upload(b, b->d_tw, tw.data(), tw.size() * sizeof(float2));
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "squelch table upload failed: %s", hipGetErrorString(e));
@@ -1330,7 +1270,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             free_bank(b);
             return rc;
         }
-        hipError_t e = hipMemcpy(b->d_fir_taps, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice);
+        hipError_t e = upload(b, b->d_fir_taps, c.data(), c.size() * sizeof(float));
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "audio FIR tap upload failed: %s", hipGetErrorString(e));
@@ -1350,7 +1290,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 free_bank(b);
                 return rc;
             }
-            hipError_t e = hipMemcpy(b->d_fm, cfg->modulation, b->n_ch, hipMemcpyHostToDevice);
+            hipError_t e = upload(b, b->d_fm, cfg->modulation, b->n_ch);
             if (e != hipSuccess) {
                 free_bank(b);
                 return fail(SDRXGPU_ERR_HIP, "modulation upload failed: %s", hipGetErrorString(e));
@@ -1388,8 +1328,8 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             free_bank(b);
             return rc;
         }
-        hipError_t e = hipMemcpy(b->d_pan_w, w.data(), w.size() * sizeof(float2), hipMemcpyHostToDevice);
-        if (e == hipSuccess && b->mix_T) e = hipMemcpy(b->d_mix_taps, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice);
+        hipError_t e = upload(b, b->d_pan_w, w.data(), w.size() * sizeof(float2));
+        if (e == hipSuccess && b->mix_T) e = upload(b, b->d_mix_taps, c.data(), c.size() * sizeof(float));
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "mix table upload failed: %s", hipGetErrorString(e));
@@ -1409,17 +1349,13 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         free_bank(b);
         return rc;
     }
-    // Everything bank_create has put on the device (tables, taps, state: blocking copies from pageable memory and memsets on the
-    // bank's stream) is complete before the bank is handed out.  Without this, a bank whose first call is the host-pointer entry
-    // leaks its translator tables at destroy -- hipFree returns success and frees nothing (hipMemGetInfo around every free; 62 MB
-    // per 3 000-channel bank; a create / process / destroy loop ran a 288 GB device out of memory after 24 000 banks).
-    {
-        const hipError_t e = hipDeviceSynchronize();
-        if (e != hipSuccess) {
-            free_bank(b);
-            return fail(SDRXGPU_ERR_HIP, "bank_create: hipDeviceSynchronize failed: %s", hipGetErrorString(e));
-        }
-    }
+    // Everything bank_create has put on the device went through the bank's own stream and is complete (upload(), init_state):
+    // no device-wide synchronisation, which would stall every other bank's streams (rounds 2-3 needed one here: see upload()).
+#if SDRX_LAB_CREATE_SYNC == 1
+    HIPCHK(hipDeviceSynchronize());
+#elif SDRX_LAB_CREATE_SYNC == 2
+    HIPCHK(hipStreamSynchronize(nullptr));
+#endif
     *out = b;
     return SDRXGPU_OK;
 }
@@ -1428,7 +1364,8 @@ extern "C" int sdrxgpu_bank_destroy(sdrxgpu_bank *b)
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_destroy: null bank");
     (void)hipSetDevice(b->device);
-    free_bank(b);
+    const int n_bad = free_bank(b);
+    if (n_bad) return fail(SDRXGPU_ERR_HIP, "bank_destroy: %d hipFree call(s) failed", n_bad);
     return SDRXGPU_OK;
 }
 
@@ -1466,11 +1403,6 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
     info->k12_bodies = (uint32_t)b->nb;
     info->matrix_pipe = b->mfma ? 1u : 0u;
     info->m_slots = b->mfma ? (uint32_t)b->n_slots_m : 0u;
-    info->bg_tail = b->bg_tail ? 1u : 0u;
-    if (b->bg_tail) {                                      // switched itself off since? (bg_claim: a wait ran out)
-        int off = 0;
-        if (hipMemcpy(&off, b->d_bg_disabled, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && off) info->bg_tail = 2u;
-    }
     return SDRXGPU_OK;
 }
 
@@ -1653,7 +1585,7 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
         M.pa.lds_bytes = (int)k12m_lds_bytes(b->mGS, b->mGT);
         if ((uint64_t)(b->n_ch + 1) * (uint64_t)b->y2_stride * sizeof(float2) >= (1ull << 32))
             return fail(SDRXGPU_ERR_HIP, "internal: stage-2 scratch of %u x %d entries exceeds k_stage12m's 32-bit byte offsets", b->n_ch, b->y2_stride);
-        HIPCHK(launch_k12m(M, M.L.args.done != nullptr, st));        // (beside k_tail_bg: the build that leaves it room)
+        HIPCHK(launch_k12m(M, st));
         return SDRXGPU_OK;
     }
     if (!b->pair) {
@@ -1745,7 +1677,6 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         L.y3 = nullptr;
         L.seam = nullptr;
         a.seam_stride = 0;
-        a.done = nullptr;
         L.W = b->W;
         L.CPW = b->CPW;
         L.grid = a.n_cgx * a.n_wt;
@@ -1861,11 +1792,8 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
 // Tail stage(s) + AGC/demod of a prepared job on the bank's stream, outputs to the given device pointers.
 // [ch_lo, ch_hi): the channels of this launch (ch_hi < 0: the whole bank); `last`: the last (or only) part of the chunk --
 // what concerns the whole bank (history copy, squelch / audio FIR / mix-down, the output count) happens with it.
-// `overlap`: the job's stage-1/2 kernel has NOT been launched yet (launch_stage12 with defer); it is launched here, on the bank's
-// stream, behind k_tail_bg on the side stream -- the tail stages of every channel whose slot groups are complete run beside it --,
-// and k_tail_s then takes what is left (whole bank, banks with bg_tail only).
 static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq_out, float *d_audio_out, size_t out_stride,
-                       size_t out_off, size_t *produced, int ch_lo = 0, int ch_hi = -1, bool last = true, bool overlap = false)
+                       size_t out_off, size_t *produced, int ch_lo = 0, int ch_hi = -1, bool last = true)
 {
     *produced = 0;
     if (!job->valid) return SDRXGPU_OK;
@@ -1919,60 +1847,6 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     } else {
         t.hist_in = b->d_hist[b->hist_cur];
         t.hist_out = b->d_hist[b->hist_cur ^ 1];
-        t.order = nullptr;
-        t.next = nullptr;
-        t.n_units = 0;
-        t.unit_shift = 0;
-        t.skipped = nullptr;
-        t.epoch = 0;
-        // k_tail_bgs (half channels, streamed) where the scratch has k_stage12m's whole-segment layout, else k_tail_bg (channels, tile by tile)
-        const bool stream_layout = t.half_split && t.P == 1 && t.spw == 16 && t.seg_len == 48 && t.hist % 2 == 0 && t.hist >= 2 && t.hist <= 768;
-        const bool bg_stream = overlap && stream_layout && bgs_lds_bytes() + k12m_lds_bytes(b->mGS, b->mGT) * 2 <= 160 * 1024;
-        if (overlap) {
-            const int nparts = (int)b->part_ch.size() - 1;
-            const int n_wt_m = (job->L.args.n_wt / b->P + b->mGT - 1) / b->mGT * b->P;      // items per set of this launch (launch_k12_parts)
-            b->bg_target += (unsigned)n_wt_m;
-            hipLaunchKernelGGL(k_bg_set, dim3(1), dim3(1), 0, b->stream, b->d_bg_next, b->d_bg_stop, 1);    // next = 0, stop = 0
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(b->ev_bg_go, b->stream));
-            HIPCHK(hipStreamWaitEvent(b->stream_bg, b->ev_bg_go, 0));
-            BgArgs g;
-            g.done = b->d_bg_done;
-            g.target = b->bg_target;
-            g.next = b->d_bg_next;
-            g.stop = b->d_bg_stop;
-            g.order = b->d_bg_order;
-            g.set_of = b->d_bg_set_of;
-            g.skipped = b->d_bg_skipped;
-            g.disabled = b->d_bg_disabled;
-            g.n_units = bg_stream ? 2 * (int)b->n_ch : (int)b->n_ch;
-            // one workgroup per CU, launched BEFORE the stage-1/2 kernel: it has its place when that kernel's workgroups arrive
-            if (bg_stream)
-                hipLaunchKernelGGL((k_tail_bgs<5, 21, 5, 67, SDRX_BGS_NB, SDRX_BGS_DEPTH>), dim3(b->bg_cus), dim3(256), bgs_lds_bytes(), b->stream_bg, t, g);
-            else
-                hipLaunchKernelGGL((k_tail_bg<5, 21, 5, 67>), dim3(b->bg_cus), dim3(256), b->tail_lds, b->stream_bg, t, g);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(b->ev_bg_done, b->stream_bg));
-            job->L.args.done = b->d_bg_done;
-            const int rc12 = launch_k12_parts(b, job, b->stream, 0, nparts);
-            // (whatever happened to that launch: the flag that ends k_tail_bg's waiting always follows)
-            hipLaunchKernelGGL(k_bg_set, dim3(1), dim3(1), 0, b->stream, b->d_bg_next, b->d_bg_stop, 0);    // stop = 1
-            const hipError_t e_stop = hipGetLastError();
-            if (rc12 || e_stop != hipSuccess) {
-                (void)hipStreamWaitEvent(b->stream, b->ev_bg_done, 0);
-                if (rc12) return rc12;
-                HIPCHK(e_stop);
-            }
-            // k_tail_s takes the units from *next on right away (k_tail_bg claims nothing after the flag; a claim that was in
-            // flight makes one channel run twice, to the same bits); k_tail_bg's last channels finish beside it and are waited
-            // for before k_agc reads the rows
-            t.order = b->d_bg_order;
-            t.next = b->d_bg_next;
-            t.n_units = (int)b->n_ch;
-            t.unit_shift = bg_stream ? 1 : 0;
-            t.skipped = b->d_bg_skipped;
-            t.epoch = b->bg_target;
-        }
         ProfScope ps(b, SDRXGPU_K_TAIL);
         const dim3 grid(((n_part + 7) / 8 * 8) * t.n_tiles);
         const int mA = t.has_a ? t.mA : 0, tA = t.has_a ? t.tA : 0;
@@ -1989,7 +1863,6 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             hipLaunchKernelGGL(k_tail, grid, dim3(256), b->tail_lds, b->stream, t);
 #undef SDRX_TAIL_CASE
         HIPCHK(hipGetLastError());
-        if (overlap) HIPCHK(hipStreamWaitEvent(b->stream, b->ev_bg_done, 0));
         if (last) b->hist_cur ^= 1;
     }
 
@@ -2109,15 +1982,9 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
                      size_t out_off, size_t *produced)
 {
     sdrxgpu_bank::TailJob job;
-    // banks with bg_tail: the stage-1/2 kernel is launched inside launch_tail, behind the background tail kernel
-    const bool overlap = b->bg_tail;
-    int rc = launch_stage12(b, in_len, b->stream, b->d_y2, &job, overlap);
+    const int rc = launch_stage12(b, in_len, b->stream, b->d_y2, &job);
     if (rc) return rc;
-    if (overlap && job.valid && job.t.n_b <= 0) {           // stage-2 outputs but no final output in this call: nothing for a tail to do
-        if ((rc = launch_k12_parts(b, &job, b->stream, 0, (int)b->part_ch.size() - 1))) return rc;
-        return launch_tail(b, &job, d_iq_out, d_audio_out, out_stride, out_off, produced);
-    }
-    return launch_tail(b, &job, d_iq_out, d_audio_out, out_stride, out_off, produced, 0, -1, true, overlap && job.valid);
+    return launch_tail(b, &job, d_iq_out, d_audio_out, out_stride, out_off, produced);
 }
 
 // Pipelined mode: stage-1/2 of THIS block on stream2, concurrently the tail + AGC of the PREVIOUS block on the

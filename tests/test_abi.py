@@ -35,17 +35,6 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(sb.EXPORTED_SYMBOLS) == decl
 
 
-def test_the_zero_wait_variant_of_the_library_is_built_and_exports_the_same_symbols(lib):
-    """build_lib.sh builds libsdrxgpu_bgwait0.so beside the product (-DSDRX_BG_WAIT_TICKS=0): what the GPU suite uses to drive the
-    background tail kernel into its time-out path.  Same sources, same ABI."""
-    path = os.path.join(os.path.dirname(sb.LIB_PATH), "libsdrxgpu_bgwait0.so")
-    if not os.path.exists(path):
-        subprocess.check_call([os.path.join(ROOT, "build_lib.sh")])
-    v = C.CDLL(path)
-    for name in _declared_symbols():
-        assert hasattr(v, name), name
-
-
 def test_no_oracle_or_torch_in_product_library(lib):
     """The product library must not link the oracle (or torch): a parity claim through the checker is void."""
     out = subprocess.check_output(["ldd", sb.LIB_PATH]).decode()

@@ -199,3 +199,46 @@ def test_creating_and_destroying_banks_returns_their_device_memory():
     torch.cuda.synchronize()
     lost = free0 - torch.cuda.mem_get_info()[0]
     assert lost < 16 << 20, "%d MB of device memory not returned by 8 banks" % (lost >> 20)
+
+
+def test_creating_a_bank_does_not_wait_for_another_banks_stream():
+    """bank_create ends with a wait for the bank's OWN stream only (rounds 2-3: hipDeviceSynchronize, which stalls every other
+    bank's streams -- config 5 runs 16 banks).  Bank A has some 100 ms of work queued; bank B is created meanwhile: the call must
+    return while A is still running, and A's outputs are what they are without the interruption."""
+    import time
+    ch = chains.chain("10")
+    n_ch = 3000
+    tabs = sb.translators_for(ch, chains.offsets_cycled(n_ch, ch.N))
+    L = ch.block_len
+    xs = [torch.from_numpy(x.view(np.float32).reshape(L, 2).copy()).cuda() for x in _blocks(ch, 2)]
+    d_iq = torch.zeros(n_ch, 512, 2, device="cuda")
+    d_au = torch.zeros(n_ch, 512, device="cuda")
+
+    def run(interrupt):
+        stream = torch.cuda.Stream()
+        a = sb.ChannelBank(tabs, ch.stage_tuples(), stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        n_steps = 400
+        for k in range(n_steps):
+            assert a.process_device(xs[k & 1].data_ptr(), L, d_iq.data_ptr(), d_au.data_ptr(), 512) == 512
+        done = torch.cuda.Event()
+        done.record(stream)
+        still_running = None
+        if interrupt:
+            t0 = time.perf_counter()
+            b = sb.ChannelBank(sb.translators_for(ch, [3, -3, 5, 0]), ch.stage_tuples())
+            t_create = time.perf_counter() - t0
+            still_running = not done.query()
+            out_b = b.process(synth.synth_iq(5, 0, L, 0.25))
+            assert out_b[0].shape == (4, 512)
+            b.close()
+            print(f"bank B created in {t_create * 1e3:.1f} ms beside bank A; A still running afterwards: {still_running}")
+        a.synchronize()
+        res = (d_iq.cpu().numpy().copy(), d_au.cpu().numpy().copy())
+        a.close()
+        return res, still_running
+
+    plain, _ = run(False)
+    got, still_running = run(True)
+    assert still_running, "bank_create returned only after the other bank's queued work had finished"
+    assert np.array_equal(plain[0].view(np.uint32), got[0].view(np.uint32)) and np.array_equal(plain[1].view(np.uint32), got[1].view(np.uint32))

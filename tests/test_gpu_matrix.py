@@ -236,73 +236,3 @@ def test_200_blocks_in_ragged_calls_through_the_matrix_pipe(oracle):
         worst_iq, worst_au = max(worst_iq, last_iq), max(worst_au, last_au)
     margin("long_stream_200_blocks[matrix_pipe]", worst_iq=worst_iq, worst_audio=worst_au, last_block_iq=last_iq, last_block_audio=last_au)
     assert worst_iq <= RTOL and worst_au <= RTOL
-
-
-@pytest.mark.parametrize("n_ch", [70, 3000, 10000])
-def test_tail_beside_the_stage12_kernel_gives_the_same_bits(n_ch):
-    """k_tail_bg (the tail stages of every channel whose slot groups are complete, beside k_stage12m) + k_tail_s for the rest
-    against the plain sequence of kernels, device entry, and against the host entry's channel parts: bit for bit.  70 channels:
-    one workgroup set, nothing is complete before the stage-1/2 kernel ends; 10 000: three rounds of workgroups."""
-    from test_gpu_entries import _blocks, _device_run
-    ch = chains.chain("10")
-    offs = chains.offsets_cycled(n_ch, ch.N)
-    tabs = sb.translators_for(ch, offs)
-    blocks = _blocks(ch, 3, car=[tabs[7]])
-    bg = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": REQ, "bg_tail": REQ})
-    assert bg.info().bg_tail == 1
-    got = _device_run(bg, blocks, n_ch, in_place=True)
-    bg.close()
-    plain = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": REQ, "bg_tail": OFF})
-    assert plain.info().bg_tail == 0 and plain.info().matrix_pipe == 1
-    want = _device_run(plain, blocks, n_ch, in_place=False)
-    plain.close()
-    for k in range(len(blocks)):
-        assert np.array_equal(got[k][0].view(np.uint32), want[k][0].view(np.uint32))
-        assert np.array_equal(got[k][1].view(np.uint32), want[k][1].view(np.uint32))
-    host = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": REQ})
-    for k, x in enumerate(blocks):
-        a, b = host.process(x)
-        assert np.array_equal(a.view(np.uint32), want[k][0].view(np.uint32))
-        assert np.array_equal(b.view(np.uint32), want[k][1].view(np.uint32))
-    host.close()
-
-
-_HANDBACK = r"""
-import sys
-import numpy as np
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
-from sdrx_amd import bank as sb, chains
-from test_gpu_entries import _blocks, _device_run
-ch = chains.chain("10")
-n_ch = 3000
-tabs = sb.translators_for(ch, chains.offsets_cycled(n_ch, ch.N))
-blocks = _blocks(ch, 3, car=[tabs[7]])
-bg = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": 2, "bg_tail": 2})
-assert bg.info().bg_tail == 1
-got = _device_run(bg, blocks, n_ch, in_place=True)
-state = bg.info().bg_tail
-bg.close()
-plain = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": 2, "bg_tail": 1})
-want = _device_run(plain, blocks, n_ch, in_place=False)
-plain.close()
-same = all(np.array_equal(g[0].view(np.uint32), w[0].view(np.uint32)) and np.array_equal(g[1].view(np.uint32), w[1].view(np.uint32))
-           for g, w in zip(got, want))
-print("HANDBACK state=%d same=%d" % (state, same))
-"""
-
-
-def test_background_tail_gives_its_channels_back_when_a_wait_runs_out():
-    """bg_claim's bounded wait: with the library built for a wait of zero ticks (build_lib.sh: libsdrxgpu_bgwait0.so) the first
-    channel whose slot groups are not complete yet goes back to k_tail_s and the background tail switches itself off
-    (bank_info.bg_tail == 2) -- and the outputs are the plain sequence's, bit for bit.  (Own process: the library is chosen at
-    import.)"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "sdrx_amd", "lib", "libsdrxgpu_bgwait0.so")
-    assert os.path.exists(lib), "build_lib.sh builds it"
-    env = dict(os.environ, SDRXGPU_LIB_PATH=lib)
-    r = subprocess.run([sys.executable, "-c", _HANDBACK, root], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert "HANDBACK state=2 same=1" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]

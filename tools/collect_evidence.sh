@@ -16,7 +16,6 @@ step 400 $E/bench.log python bench.py
 step 200 $E/bench_vector.log python bench.py --matrix 1 --no-cpu-baseline --no-extra-configs
 step 200 $E/bench_vector_separate_tail.log python bench.py --matrix 1 --fused 1 --no-cpu-baseline --no-extra-configs
 step 200 $E/bench_rccl_1rank.log python bench.py --force-dist --no-cpu-baseline --no-extra-configs
-step 200 $E/bench_bg_tail.log python bench.py --bg-tail 2 --no-cpu-baseline --no-extra-configs
 step 60 $E/ubench_valu.txt tools/ubench_valu.bin
 step 60 $E/ubench_hbm_read.txt tools/ubench_hbm_read.bin
 step 120 $E/ubench_mfma_fir.txt tools/ubench_mfma_fir.bin

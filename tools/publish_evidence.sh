@@ -8,7 +8,6 @@ j $E/bench.log $P/${T}_bench.json
 j $E/bench_vector.log $P/${T}_bench_vector_kernels.json
 j $E/bench_vector_separate_tail.log $P/${T}_bench_vector_kernels_separate_tail.json
 j $E/bench_rccl_1rank.log $P/${T}_bench_rccl_1rank.json
-j $E/bench_bg_tail.log $P/${T}_bench_bg_tail.json
 j $E/bench_under_rocprof_trace.log $P/${T}_bench_under_rocprof.json
 j $E/bench_under_rocprof_trace_vector.log $P/${T}_bench_under_rocprof_vector_kernels.json
 cp "$(ls -t $E/trace/runc/*_kernel_stats.csv | head -1)" $P/${T}_kernel_stats.csv
