@@ -5,6 +5,8 @@
 // Operands come from a static LDS tile (no refill: this measures the pipes, not the memory system).
 //   MODE 0: MFMAs + their LDS operand reads only      MODE 1: + coefficient build (t*h), tap 16, combinations
 //   MODE 2: + stage 2 (the whole phase)                MODE 3: VALU part only (no MFMA)
+//   MODE 4: stages 2 and 3 as ONE 119-tap filter in transposed form instead of stage 2: six rotating accumulator sets per value,
+//           six per-lane coefficients per phase read from an LDS table (round 4: what a fused stage 3 would cost the phase)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +23,7 @@ __global__ __launch_bounds__(256, WPS) void k(const float2 *__restrict__ src, fl
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < ROWS * PITCH / 8; i += 256) reinterpret_cast<float2 *>(lds)[i] = src[(blockIdx.x * 131 + i) & 0xffff];
+    for (int i = tid; i < (ROWS * PITCH + 170 * 32) / 8; i += 256) reinterpret_cast<float2 *>(lds)[i] = src[(blockIdx.x * 131 + i) & 0xffff];
     __syncthreads();
     const int lo = lane & 15, hi = lane >> 4;
     const char *tA = lds + lo * PITCH + hi * 8;                 // A operand: t[slot lo][5p + 4j + hi]
@@ -39,6 +41,13 @@ __global__ __launch_bounds__(256, WPS) void k(const float2 *__restrict__ src, fl
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int i = 0; i < 8; i++) acc2[a][i] = v2f{0.f, 0.f};
+    v2f acc6[6][8];                                            // MODE 4: combined stage-2/3 accumulators
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc6[a][i] = v2f{0.f, 0.f};
+    // MODE 4: per-lane row of the coefficient table (five phase classes among the 16 segments), 32-byte rows behind the tiles
+    const char *wrow = lds + ROWS * PITCH + ((lo % 5) * 7 % 150) * 32;
     v2f ysum[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) ysum[i] = v2f{0.f, 0.f};
@@ -106,7 +115,23 @@ __global__ __launch_bounds__(256, WPS) void k(const float2 *__restrict__ src, fl
             Y[0] = v2f{c.Pr[0], c.Pr[1]}; Y[1] = v2f{c.Pr[2], c.Pr[3]}; Y[2] = v2f{c.Pi[0], c.Pi[1]}; Y[3] = v2f{c.Pi[2], c.Pi[3]};
             Y[4] = v2f{c.Qr[0], c.Qr[1]}; Y[5] = v2f{c.Qr[2], c.Qr[3]}; Y[6] = v2f{c.Qi[0], c.Qi[1]}; Y[7] = v2f{c.Qi[2], c.Qi[3]};
         }
-        if (MODE >= 2) {
+        if (MODE == 4) {
+            // six per-lane coefficients of this phase: one 16-byte and one 8-byte LDS read at a per-lane address
+            const v4f c03 = *reinterpret_cast<const v4f *>(wrow + boff + p * 32);
+            const v2f c45 = *reinterpret_cast<const v2f *>(wrow + boff + p * 32 + 16);
+            const v2f cp[3] = {v2f{c03.x, c03.y}, v2f{c03.z, c03.w}, c45};
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if ((a & 1) == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc6[a][i]) : "v"(Y[i]), "v"(cp[a >> 1]));
+                    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc6[a][i]) : "v"(Y[i]), "v"(cp[a >> 1]));
+                }
+            if (p == 7) {       // (stands in for the store + reset of a finished set, once per 20 phases here, per 25 in the kernel)
+#pragma unroll
+                for (int i = 0; i < 8; i++) { ysum[i] += acc6[2][i]; acc6[2][i] = v2f{0.f, 0.f}; }
+            }
+        } else if (MODE >= 2) {
             // transposed-form stage 2: input u = p % 5 of super-step s = p / 5 feeds the outputs s, s-1, s-2, (s-3)
             const int u = p % 5, s = p / 5;
 #pragma unroll
@@ -208,13 +233,17 @@ int main()
     float *h2;
     hipMalloc(&h2, sizeof(h2h));
     hipMemcpy(h2, h2h, sizeof(h2h), hipMemcpyHostToDevice);
+    if (getenv("UBENCH_ALL")) {
     run<0, 1>("mfma + operand reads", 1, src, h2);
     run<1, 1>("+ coefficients, tap 16, combos", 1, src, h2);
     run<2, 1>("+ stage 2 (whole phase)", 1, src, h2);
     run<3, 1>("VALU part only", 1, src, h2);
+    }
     run<0, 2>("mfma + operand reads", 2, src, h2);
     run<1, 2>("+ coefficients, tap 16, combos", 2, src, h2);
     run<2, 2>("+ stage 2 (whole phase)", 2, src, h2);
     run<3, 2>("VALU part only", 2, src, h2);
+    run<4, 1>("stages 2+3 as one transposed filter", 1, src, h2);
+    run<4, 2>("stages 2+3 as one transposed filter", 2, src, h2);
     return 0;
 }
