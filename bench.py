@@ -52,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--block-hint", type=int, default=0)
     ap.add_argument("--fused", type=int, default=0, help="tuning.fused_tail: 0 auto, 1 separate tail kernel, 2 require the fused path")
     ap.add_argument("--pair", type=int, default=0, help="tuning.pair_lanes: 0 auto, 1 one channel per lane, 2 require two channels per lane")
-    ap.add_argument("--matrix", type=int, default=0, help="tuning.matrix_pipe: 0 auto, 1 vector kernels only, 2 require k_stage12m (mixer + stage 1 on the f32 matrix pipe)")
+    ap.add_argument("--matrix", type=int, default=0, help="tuning.matrix_pipe: 0 auto, 1 vector kernels only, 2 require k_stage12m (mixer + stage 1 on the f32 matrix pipe; k_tail_s behind it), 3 require k_stage123m (+ stages 2-3 in the same kernel, no stage-2 scratch; k_tail_c behind it)")
     ap.add_argument("--mgs", type=int, default=0, help="tuning.m_slot_groups (k_stage12m workgroup shape), 0 auto")
     ap.add_argument("--mgt", type=int, default=0, help="tuning.m_seg_groups, 0 auto")
     ap.add_argument("--tail-tile", type=int, default=0, help="tuning.tail_tile (final outputs per workgroup of the separate tail kernel), 0 auto")

@@ -4,6 +4,7 @@
 #include "../../include/sdrx_gpu.h"
 #include "kernels.hpp"
 #include "kernels_mfma.hpp"
+#include "kernels_mfma3.hpp"
 
 #include <algorithm>
 #include <complex>
@@ -332,6 +333,52 @@ static hipError_t k12m_set_attributes(int GS, int GT)
     return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, n);
 }
 
+// mixer + stages 1-3 without a stage-2 scratch (k_stage123m, kernels_mfma3.hpp): same workgroup shapes as k_stage12m
+struct K123mLaunch {
+    const float2 *x, *tables;
+    float2 *y3c;
+    Stage123Args args;
+    PairArgs pa;
+    const float *h1;
+    int GS, GT, grid;
+};
+
+static size_t k123m_lds_bytes(int GS, int GT)
+{
+    if (GS == 2 && GT == 2) return TileGeomM3<2, 2>::lds_bytes;
+    if (GS == 4 && GT == 2) return TileGeomM3<4, 2>::lds_bytes;
+    return TileGeomM3<2, 4>::lds_bytes;
+}
+
+template <int GS, int GT>
+static hipError_t launch_k123m_one(const K123mLaunch &M, const Stage123mTaps &taps, hipStream_t s)
+{
+    using TG = TileGeomM3<GS, GT>;
+    static_assert(TG::lds_bytes <= 160 * 1024, "tile buffers + coefficient table must fit the LDS");
+    hipLaunchKernelGGL((k_stage123m<GS, GT>), dim3(M.grid), dim3(64 * GS * GT), TG::lds_bytes, s, M.x, M.tables, M.y3c, M.args, M.pa, taps);
+    return hipGetLastError();
+}
+
+static hipError_t launch_k123m(const K123mLaunch &M, hipStream_t s)
+{
+    Stage123mTaps taps{};
+    for (int i = 0; i < 17; i++) taps.h1[i] = M.h1[i < 9 ? i : 16 - i];       // (the reference reads h[0 .. half] only, msd.hpp:309-331)
+    if (M.GS == 2 && M.GT == 2) return launch_k123m_one<2, 2>(M, taps, s);
+    if (M.GS == 4 && M.GT == 2) return launch_k123m_one<4, 2>(M, taps, s);
+    if (M.GS == 2 && M.GT == 4) return launch_k123m_one<2, 4>(M, taps, s);
+    return hipErrorInvalidValue;
+}
+
+static hipError_t k123m_set_attributes(int GS, int GT)
+{
+    const void *f = nullptr;
+    if (GS == 2 && GT == 2) f = reinterpret_cast<const void *>(&k_stage123m<2, 2>);
+    if (GS == 4 && GT == 2) f = reinterpret_cast<const void *>(&k_stage123m<4, 2>);
+    if (GS == 2 && GT == 4) f = reinterpret_cast<const void *>(&k_stage123m<2, 4>);
+    if (!f) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k123m_lds_bytes(GS, GT));
+}
+
 struct K12Entry {
     int M1, T1, M2, T2, Y2B;
     int level;
@@ -445,6 +492,8 @@ struct sdrxgpu_bank {
         TailArgs t;
         int c0 = 0, n_y3 = 0, d0 = 0, n_bnd = 0;   // fused banks (Tail4Args)
         K12Launch L;                                // the stage-1/2 launch of this chunk (launch_k12_range)
+        K123mLaunch M3;                             // banks on k_stage123m: its launch, and what k_tail_c needs of the call
+        int n_y1 = 0, k25 = 0, r0m6 = 0, n_out3 = 0, n_seg = 0;
         const float2 *roll_from = nullptr;   // input-history copy left for k_agc to do (serial mode)
         float2 *roll_to = nullptr;
         int roll_cnt = 0;
@@ -459,6 +508,13 @@ struct sdrxgpu_bank {
     // ordered by host part, every part's share padded to whole workgroup sets of 16 * mGS slots
     bool mfma = false;
     int mGS = 2, mGT = 2;
+    // ... and stages 2-3 behind it in the same kernel, no stage-2 scratch (k_stage123m + k_tail_c, kernels_mfma3.hpp): the
+    // coefficient table of the combined stage-2/3 filter, the stage-3 scratch [channel][segment group][entry][segment] and, per
+    // channel, the last H3c stage-3 outputs of the stream followed by the six partial sums in flight (+ 2 of padding)
+    bool mfma3 = false;
+    float *d_wtab = nullptr;
+    float2 *d_y3c = nullptr, *d_hist3c[2] = {nullptr, nullptr};    // (histories: ping-pong between calls, as d_hist)
+    int y3c_stride = 0, H3c = 80;
     int2 *d_slots_m = nullptr, *d_slots_mp = nullptr;  // partners from the whole bank / from inside each host part
     int n_slots_m = 0, n_slots_mp = 0, n_pairs_m = 0;
     std::vector<int> part_gm;                         // set boundaries of the host parts
@@ -566,6 +622,10 @@ static int free_bank(sdrxgpu_bank *b)
     fr(b->d_seam);
     fr(b->d_slots);
     fr(b->d_slots_m);
+    fr(b->d_wtab);
+    fr(b->d_y3c);
+    fr(b->d_hist3c[0]);
+    fr(b->d_hist3c[1]);
     fr(b->d_group_conj);
     fr(b->d_keep);
     fr(b->d_audio_keep);
@@ -602,8 +662,11 @@ static int init_state(sdrxgpu_bank *b)
     HIPCHK(hipMemsetAsync(b->d_xr[0], 0, b->x_capacity * sizeof(float2), b->stream));
     HIPCHK(hipMemsetAsync(b->d_xr[1], 0, b->x_capacity * sizeof(float2), b->stream));
     b->xr = 0;
-    HIPCHK(hipMemsetAsync(b->d_y2, 0, (size_t)b->n_ch * b->y2_stride * sizeof(float2), b->stream));
-    if (b->fused) {
+    if (b->d_y2) HIPCHK(hipMemsetAsync(b->d_y2, 0, (size_t)b->n_ch * b->y2_stride * sizeof(float2), b->stream));
+    if (b->mfma3) {
+        HIPCHK(hipMemsetAsync(b->d_hist3c[0], 0, (size_t)b->n_ch * (b->H3c + 8) * sizeof(float2), b->stream));
+        HIPCHK(hipMemsetAsync(b->d_hist3c[1], 0, (size_t)b->n_ch * (b->H3c + 8) * sizeof(float2), b->stream));
+    } else if (b->fused) {
         HIPCHK(hipMemsetAsync(b->d_y3, 0, (size_t)b->n_ch * b->y3_stride * sizeof(float2), b->stream));
         HIPCHK(hipMemsetAsync(b->d_hist2, 0, (size_t)b->n_ch * b->H2 * sizeof(float2), b->stream));
         HIPCHK(hipMemsetAsync(b->d_hist3, 0, (size_t)b->n_ch * b->H3 * sizeof(float2), b->stream));
@@ -738,9 +801,19 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     const sdrxgpu_tuning tune0 = cfg->tuning ? *cfg->tuning : sdrxgpu_tuning{};
     {
         const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && N > 0 && (N % 2) == 0;
-        if (tune0.matrix_pipe > 2) {
+        // ... and k_stage123m (stages 2-3 in the same kernel, k_tail_c behind it): the whole 10 MS/s chain with N = 1 200, whole
+        // segments per lane, the call cut nowhere else (not pipelined: one scratch)
+        const bool can3 = can && N == 1200 && cfg->n_stages == 4 && cfg->stages[2].m == 5 && cfg->stages[2].n_taps == 21 &&
+                          cfg->stages[3].m == 5 && cfg->stages[3].n_taps == 67 && !b->pipelined && !tune0.tail_generic &&
+                          (cfg->block_hint == 0 || cfg->block_hint == 0xFFFFFFFFu);
+        if (tune0.matrix_pipe > 3) {
             free_bank(b);
-            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe %u (0..2)", tune0.matrix_pipe);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe %u (0..3)", tune0.matrix_pipe);
+        }
+        if (tune0.matrix_pipe == 3 && !can3) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = 3, but k_stage123m is built for the whole 10 MS/s chain "
+                        "((5,17)(5,19)(5,21)(5,67), N = 1200), not pipelined, whole segments per lane");
         }
         if (tune0.matrix_pipe == 2 && !can) {
             free_bank(b);
@@ -750,11 +823,12 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         // (automatic only where nothing else about the stage-1/2 kernel is asked for: a required fused tail, required pair lanes
         // or a forced geometry mean the vector kernels)
         const bool others = tune0.fused_tail == 2 || tune0.pair_lanes == 2 || tune0.k12_waves || tune0.k12_cpw;
-        if (tune0.matrix_pipe == 2 && others) {
+        if (tune0.matrix_pipe >= 2 && others) {
             free_bank(b);
-            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe = 2 goes with neither fused_tail = 2, pair_lanes = 2 nor k12_waves / k12_cpw");
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe = 2 / 3 goes with neither fused_tail = 2, pair_lanes = 2 nor k12_waves / k12_cpw");
         }
-        b->mfma = can && (tune0.matrix_pipe == 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 3584));
+        b->mfma = can && (tune0.matrix_pipe >= 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 3584));
+        b->mfma3 = b->mfma && can3 && (tune0.matrix_pipe == 3 || tune0.matrix_pipe == 0);
         if (b->mfma) {
             b->mGS = tune0.m_slot_groups ? (int)tune0.m_slot_groups : 2;
             b->mGT = tune0.m_seg_groups ? (int)tune0.m_seg_groups : 2;
@@ -777,7 +851,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = 2, but %u tables of %d entries exceed k_stage12m's 32-bit row offsets",
                         b->n_ch, b->tbl_stride);
         }
-        b->mfma = false;                                        // automatic choice: the vector kernels
+        b->mfma = b->mfma3 = false;                             // automatic choice: the vector kernels
         b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
     }
 
@@ -942,7 +1016,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 }
             }
         }
-        if (cfg->block_hint == 0xFFFFFFFFu) {
+        if (cfg->block_hint == 0xFFFFFFFFu || b->mfma3) {
             b->nb = b->bps;                   // whole segment per lane (P == 1)
         } else if (cfg->block_hint) {
             if (b->bps % cfg->block_hint) {
@@ -1142,9 +1216,33 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         hipError_t e = upload(b, b->d_slots_m, slots_all.data(), slots_all.size() * sizeof(int2));
         if (e == hipSuccess) e = upload(b, b->d_slots_mp, slots_parts.data(), slots_parts.size() * sizeof(int2));
         if (e == hipSuccess) e = k12m_set_attributes(b->mGS, b->mGT);
+        if (e == hipSuccess && b->mfma3) e = k123m_set_attributes(b->mGS, b->mGT);
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "k_stage12m set-up failed: %s", hipGetErrorString(e));
+        }
+        if (b->mfma3) {
+            // stages 2 and 3 as one filter on the stage-1 outputs: H[5 e3 + e2] += h3[e3] h2[e2], in double, rounded to fp32 once;
+            // table row tau = the six slots' coefficients for a lane in phase tau (fused_index.hpp), rows 150 .. 158 repeat rows 0 .. 8
+            double H[fx::NTAP] = {};
+            for (size_t e3 = 0; e3 < b->taps[2].size(); e3++)
+                for (size_t e2 = 0; e2 < b->taps[1].size(); e2++) H[5 * e3 + e2] += (double)b->taps[2][e3] * (double)b->taps[1][e2];
+            std::vector<float> w((size_t)fx::WROWS * 8, 0.0f);
+            for (int r = 0; r < fx::WROWS - 1; r++)
+                for (int q = 0; q < fx::NSLOT; q++) {
+                    const int ee = ((r % fx::PERIOD) - 25 * q + 94 + fx::PERIOD) % fx::PERIOD;
+                    w[(size_t)r * 8 + q] = ee < fx::NTAP ? (float)H[ee] : 0.0f;
+                }
+            if ((rc2 = dev_alloc(b, (void **)&b->d_wtab, w.size() * sizeof(float)))) {
+                free_bank(b);
+                return rc2;
+            }
+            e = upload(b, b->d_wtab, w.data(), w.size() * sizeof(float));
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_c<5, 67>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (e != hipSuccess) {
+                free_bank(b);
+                return fail(SDRXGPU_ERR_HIP, "k_stage123m set-up failed: %s", hipGetErrorString(e));
+            }
         }
     }
 
@@ -1156,16 +1254,29 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         const long long G = ((long long)max_y2 / k12->Y2B + (long long)SPW * b->bps) / ((long long)SPW * b->bps) + 1;
         // body-major stage-2 rows: whole time-waves of SPW segments x bps bodies x Y2B outputs
         b->y2_stride = (int)((G * SPW * b->bps * k12->Y2B + 63) / 64 * 64);
+        if (b->mfma3) {
+            // segment groups of 16 segments of 240 stage-1 outputs, rounded up to whole workgroups of mGT groups; 16 entries x 16 segments each
+            const long long n_seg = ((long long)b->max_chunk / k12->M1 + 1 + fx::LSEG - 1) / fx::LSEG;
+            const long long groups = ((n_seg + 15) / 16 + b->mGT - 1) / b->mGT * b->mGT;
+            b->y3c_stride = (int)(groups * fx::NENT * 16);
+            if ((uint64_t)(b->n_ch + 1) * (uint64_t)b->y3c_stride * sizeof(float2) >= (1ull << 32)) {
+                free_bank(b);
+                return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: stage-3 scratch of %u x %d entries exceeds k_stage123m's 32-bit byte offsets", b->n_ch, b->y3c_stride);
+            }
+        }
         b->x_capacity = (size_t)b->HIST + 2 + b->max_chunk + (size_t)G * SPW * b->spacing + (size_t)(b->WU + 2) * b->SB;
     }
     int rc;
     if ((rc = dev_alloc(b, (void **)&b->d_xr[0], b->x_capacity * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_xr[1], b->x_capacity * sizeof(float2))) ||
         (rc = dev_alloc(b, (void **)&b->d_tables, 2 * (size_t)b->n_ch * b->tbl_stride * sizeof(float2))) ||
-        (rc = dev_alloc(b, (void **)&b->d_y2, ((size_t)b->n_ch + (b->mfma ? 1 : 0)) * b->y2_stride * sizeof(float2))) ||   // (k_stage12m: a spare row for places without channel)
+        (!b->mfma3 && (rc = dev_alloc(b, (void **)&b->d_y2, ((size_t)b->n_ch + (b->mfma ? 1 : 0)) * b->y2_stride * sizeof(float2)))) ||   // (k_stage12m: a spare row for places without channel)
+        (b->mfma3 && (rc = dev_alloc(b, (void **)&b->d_y3c, ((size_t)b->n_ch + 1) * b->y3c_stride * sizeof(float2)))) ||
+        (b->mfma3 && (rc = dev_alloc(b, (void **)&b->d_hist3c[0], (size_t)b->n_ch * (b->H3c + 8) * sizeof(float2)))) ||
+        (b->mfma3 && (rc = dev_alloc(b, (void **)&b->d_hist3c[1], (size_t)b->n_ch * (b->H3c + 8) * sizeof(float2)))) ||
         (b->pipelined && (rc = dev_alloc(b, (void **)&b->d_y2b, ((size_t)b->n_ch + (b->mfma ? 1 : 0)) * b->y2_stride * sizeof(float2)))) ||
-        (!b->fused && (rc = dev_alloc(b, (void **)&b->d_hist[0], (size_t)b->n_ch * b->y2_hist * sizeof(float2)))) ||
-        (!b->fused && (rc = dev_alloc(b, (void **)&b->d_hist[1], (size_t)b->n_ch * b->y2_hist * sizeof(float2)))) ||
+        (!b->fused && !b->mfma3 && (rc = dev_alloc(b, (void **)&b->d_hist[0], (size_t)b->n_ch * b->y2_hist * sizeof(float2)))) ||
+        (!b->fused && !b->mfma3 && (rc = dev_alloc(b, (void **)&b->d_hist[1], (size_t)b->n_ch * b->y2_hist * sizeof(float2)))) ||
         (b->fused && (rc = dev_alloc(b, (void **)&b->d_y3, (size_t)b->n_ch * b->y3_stride * sizeof(float2)))) ||
         (b->fused && (rc = dev_alloc(b, (void **)&b->d_hist2, (size_t)b->n_ch * b->H2 * sizeof(float2)))) ||
         (b->fused && (rc = dev_alloc(b, (void **)&b->d_hist3, (size_t)b->n_ch * b->H3 * sizeof(float2)))) ||
@@ -1401,7 +1512,7 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
     info->k12_waves = (uint32_t)b->W;
     info->k12_cpw = (uint32_t)b->CPW;
     info->k12_bodies = (uint32_t)b->nb;
-    info->matrix_pipe = b->mfma ? 1u : 0u;
+    info->matrix_pipe = b->mfma3 ? 2u : b->mfma ? 1u : 0u;
     info->m_slots = b->mfma ? (uint32_t)b->n_slots_m : 0u;
     return SDRXGPU_OK;
 }
@@ -1418,7 +1529,9 @@ extern "C" int sdrxgpu_bank_ingest_buffer(sdrxgpu_bank *b, void **d_ptr, size_t 
 // first body would otherwise start on an odd index of the ring (16-byte LDS-DMA sources)
 static long long origin_after(const sdrxgpu_bank *b, long long n1)
 {
-    const long long s0_next = (n1 / b->MM) * b->MM;
+    // (k_stage123m's rows start at a stage-1 output's window, any stage-1 output: anchor = M1)
+    const long long anchor = b->mfma3 ? b->k12->M1 : b->MM;
+    const long long s0_next = (n1 / anchor) * anchor;
     long long origin_next = n1 - b->HIST;
     if ((origin_next - s0_next) & 1) origin_next -= 1;
     return origin_next;
@@ -1560,8 +1673,11 @@ static size_t outputs_of(const sdrxgpu_bank *b, uint64_t n0, size_t len)
 static int launch_k12_range(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStream_t st, int cg_lo, int cg_hi);
 
 // Launch the stage-1/2 kernel of a prepared chunk for the host parts [p_lo, p_hi) (all of them: the whole bank).
+static int launch_k123_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStream_t st, int p_lo, int p_hi);
+
 static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStream_t st, int p_lo, int p_hi)
 {
+    if (b->mfma3) return launch_k123_parts(b, job, st, p_lo, p_hi);
     if (b->mfma) {
         ProfScope ps(b, SDRXGPU_K_STAGE12, st);
         const bool whole = p_lo == 0 && p_hi == (int)b->part_ch.size() - 1;
@@ -1624,9 +1740,130 @@ static int launch_k12_range(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
     return SDRXGPU_OK;
 }
 
+// keep the last HIST (+1 when the next call's first body would otherwise start on an odd index) input samples in front of the
+// next block
+static int prepare_roll(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, long long n1, hipStream_t st)
+{
+    const long long origin_next = origin_after(b, n1);
+    const int src_off = (int)(origin_next - b->x_origin);
+    const int cnt = (int)(n1 - origin_next);
+    if (src_off < 0) return fail(SDRXGPU_ERR_HIP, "internal: history roll offset %d < 0", src_off);
+    if (cnt > 1024) return fail(SDRXGPU_ERR_HIP, "internal: history roll of %d samples", cnt);
+    // the history goes to the head of the OTHER ring, which the next chunk is read from (its block may already be
+    // arriving there behind the history's place).  Serial mode: the copy rides along with k_agc of the same
+    // chunk (launch_tail), when there is one
+    job->roll_from = b->d_xr[b->xr] + src_off;
+    job->roll_to = b->d_xr[b->xr ^ 1];
+    job->roll_cnt = cnt;
+    if (b->pipelined || !job->valid || job->t.n_b <= 0) {
+        if (job->roll_cnt) {
+            hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(1024), 0, st, job->roll_from, job->roll_to, cnt);
+            HIPCHK(hipGetLastError());
+        }
+        job->roll_cnt = 0;
+    }
+    b->x_origin = origin_next;
+    b->xr ^= 1;
+    return SDRXGPU_OK;
+}
+
+// Launch k_stage123m of a prepared chunk for the host parts [p_lo, p_hi) (all of them: the whole bank).
+static int launch_k123_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStream_t st, int p_lo, int p_hi)
+{
+    ProfScope ps(b, SDRXGPU_K_STAGE12, st);
+    const bool whole = p_lo == 0 && p_hi == (int)b->part_ch.size() - 1;
+    const int g_lo = whole ? 0 : b->part_gm[p_lo], g_hi = whole ? b->n_slots_m / (16 * b->mGS) : b->part_gm[p_hi];
+    if (g_hi <= g_lo) return SDRXGPU_OK;
+    K123mLaunch M = job->M3;
+    M.args.cg0 = g_lo;
+    M.args.n_chgroups = g_hi;
+    M.args.n_cgx = (g_hi - g_lo + 7) / 8 * 8;
+    M.grid = M.args.n_cgx * M.args.n_wt;
+    M.pa.slots = whole ? b->d_slots_m : b->d_slots_mp;
+    M.pa.group_conj = nullptr;
+    M.pa.n_slots = whole ? b->n_slots_m : b->n_slots_mp;
+    M.pa.lds_bytes = (int)k123m_lds_bytes(b->mGS, b->mGT);
+    HIPCHK(launch_k123m(M, st));
+    return SDRXGPU_OK;
+}
+
+// Banks on k_stage123m (kernels_mfma3.hpp): the call's stage-1 outputs are cut into segments of 240 from the call's start; no
+// history but the input ring's (the first stage-1 window reaches T1 - M1 samples back).
+static int launch_stage123(sdrxgpu_bank *b, size_t in_len, hipStream_t st, sdrxgpu_bank::TailJob *job, bool defer)
+{
+    const K12Entry *k = b->k12;
+    const long long n0 = (long long)b->n_in, n1 = n0 + (long long)in_len;
+    const long long k0 = n0 / k->M1, k1 = n1 / k->M1;               // stage-1 outputs before / after this call
+    const int n_y1 = (int)(k1 - k0);
+    job->valid = false;
+    if (n_y1 > 0) {
+        K123mLaunch &M = job->M3;
+        Stage123Args &a = M.args;
+        const long long first = k0 * k->M1 - (k->T1 - k->M1);       // abs index of the first sample of stage-1 output k0's window
+        const long long tshift = b->ftfir ? (long long)(k->M1 - 1) : 0;      // (--ftfir: see launch_stage12)
+        const long long tph_abs = (((first - tshift) % b->Neff) + b->Neff) % b->Neff;
+        const int tcopy = (int)(tph_abs & 1);
+        M.x = b->d_xr[b->xr];
+        M.tables = b->d_tables + (size_t)tcopy * b->n_ch * b->tbl_stride;
+        M.y3c = b->d_y3c;
+        M.h1 = b->taps[0].data();
+        M.GS = b->mGS;
+        M.GT = b->mGT;
+        a.n_ch = (int)b->n_ch;
+        a.tbl_stride = b->tbl_stride;
+        a.N = b->Neff;
+        a.n_y1 = n_y1;
+        a.x_base = (int)(first - b->x_origin);
+        a.tphase0 = (int)(tph_abs - tcopy);
+        a.kph = (int)(k0 % fx::PERIOD);
+        const int n_seg = (n_y1 + fx::LSEG - 1) / fx::LSEG;
+        const int n_grp = (n_seg + 15) / 16;
+        a.n_wt = (n_grp + b->mGT - 1) / b->mGT;
+        a.y3c_stride = b->y3c_stride;
+        a.wtab = b->d_wtab;
+        if (first < b->x_origin || (a.x_base & 1) || (a.tphase0 & 1))
+            return fail(SDRXGPU_ERR_HIP, "internal: x_base %d / tphase0 %d must be even and >= 0", a.x_base, a.tphase0);
+        const size_t x_need = (size_t)a.x_base + (size_t)n_seg * b->Neff + 64;
+        if (x_need > b->x_capacity) return fail(SDRXGPU_ERR_HIP, "internal: input ring too small (%zu > %zu)", x_need, b->x_capacity);
+        if (a.n_wt * b->mGT * fx::NENT * 16 > b->y3c_stride)
+            return fail(SDRXGPU_ERR_HIP, "internal: %d segment groups exceed the stage-3 scratch", a.n_wt * b->mGT);
+        job->n_y1 = n_y1;
+        job->k25 = (int)(k0 % 25);
+        job->r0m6 = (int)((k0 / 25) % fx::NSLOT);
+        job->n_seg = n_seg;
+        const long long r0 = n0 / (k->M1 * k->M2 * k->MA), r1 = n1 / (k->M1 * k->M2 * k->MA);     // stage-3 outputs before / after
+        job->n_out3 = (int)(r1 - r0);
+        const long long q0 = r0 / k->MB;
+        job->d0 = (int)(k->MB * q0 + k->MB - 1 - r0);
+        if (!defer) {
+            const int rc = launch_k123_parts(b, job, st, 0, (int)b->part_ch.size() - 1);
+            if (rc) return rc;
+        }
+        TailArgs &t = job->t;
+        memset(&t, 0, sizeof(t));
+        t.n_ch = (int)b->n_ch;
+        t.keep_stride = b->keep_stride;
+        t.iq_keep = b->d_keep;
+        t.mB = k->MB;
+        t.tB = k->TB;
+        for (int i = 0; i < (t.tB + 1) / 2; i++) t.hB[i] = b->taps[3][i];
+        t.n_b = (int)(n1 / b->m_total - n0 / b->m_total);
+        if (t.n_b > b->keep_stride) return fail(SDRXGPU_ERR_HIP, "internal: %d outputs > keep_stride %d", t.n_b, b->keep_stride);
+        if (job->n_out3 + b->H3c + 2 > 8000) return fail(SDRXGPU_ERR_HIP, "internal: %d stage-3 outputs exceed k_tail_c's LDS row", job->n_out3);
+        job->valid = true;
+    }
+    {
+        const int rc = prepare_roll(b, job, n1, st);
+        if (rc) return rc;
+    }
+    b->n_in += in_len;
+    return SDRXGPU_OK;
+}
+
 // `defer`: prepare only (the caller launches the stage-1/2 kernel itself, by channel ranges: launch_k12_range)
 static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2 *y2buf, sdrxgpu_bank::TailJob *job, bool defer = false)
 {
+    if (b->mfma3) return launch_stage123(b, in_len, st, job, defer);
     const K12Entry *k = b->k12;
     const long long n0 = (long long)b->n_in, n1 = n0 + (long long)in_len;
     const long long j0 = n0 / b->MM, j1 = n1 / b->MM;
@@ -1761,29 +1998,9 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         job->valid = true;
     }
 
-    // keep the last HIST (+1 when the next call's first body would otherwise start on an odd index)
-    // input samples in front of the next block
     {
-        const long long origin_next = origin_after(b, n1);
-        const int src_off = (int)(origin_next - b->x_origin);
-        const int cnt = (int)(n1 - origin_next);
-        if (src_off < 0) return fail(SDRXGPU_ERR_HIP, "internal: history roll offset %d < 0", src_off);
-        if (cnt > 1024) return fail(SDRXGPU_ERR_HIP, "internal: history roll of %d samples", cnt);
-        // the history goes to the head of the OTHER ring, which the next chunk is read from (its block may already be
-        // arriving there behind the history's place).  Serial mode: the copy rides along with k_agc of the same
-        // chunk (launch_tail), when there is one
-        job->roll_from = b->d_xr[b->xr] + src_off;
-        job->roll_to = b->d_xr[b->xr ^ 1];
-        job->roll_cnt = cnt;
-        if (b->pipelined || !job->valid || job->t.n_b <= 0) {
-            if (job->roll_cnt) {
-                hipLaunchKernelGGL(k_roll_history, dim3(1), dim3(1024), 0, st, job->roll_from, job->roll_to, cnt);
-                HIPCHK(hipGetLastError());
-            }
-            job->roll_cnt = 0;
-        }
-        b->x_origin = origin_next;
-        b->xr ^= 1;
+        const int rc = prepare_roll(b, job, n1, st);
+        if (rc) return rc;
     }
     b->n_in += in_len;
     return SDRXGPU_OK;
@@ -1817,7 +2034,29 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     t.iq_keep = iq_direct ? nullptr : b->d_keep;
     const float2 *iq_rows = iq_direct ? t.iq_out : b->d_keep;
     const int iq_rows_stride = iq_direct ? (int)out_stride : b->keep_stride;
-    if (b->fused) {
+    if (b->mfma3) {
+        // stage-3 outputs put together from k_stage123m's entries + last stage, one workgroup per channel (k_tail_c)
+        TailCArgs f;
+        f.t = t;
+        f.y3c = b->d_y3c;
+        f.y3c_stride = b->y3c_stride;
+        f.hist_in = b->d_hist3c[b->hist_cur];
+        f.hist_out = b->d_hist3c[b->hist_cur ^ 1];
+        f.H3 = b->H3c;
+        f.n_y1 = job->n_y1;
+        f.k25 = job->k25;
+        f.r0m6 = job->r0m6;
+        f.n_out3 = job->n_out3;
+        f.d0 = job->d0;
+        f.n_seg = job->n_seg;
+        f.n_tiles = std::max(1, (t.n_b + kTailCTile - 1) / kTailCTile);
+        ProfScope ps(b, SDRXGPU_K_TAIL);
+        // LDS: the tile's stage-3 outputs (5 x 128 of its own, TB - 1 before them, the next call's history: <= 816) + 16 entries of <= 96 segments
+        const size_t lds = (size_t)(816 + kTailCMaxGrp * fx::NENT * 16) * sizeof(float2);
+        hipLaunchKernelGGL((k_tail_c<5, 67>), dim3(((n_part + 7) / 8 * 8) * f.n_tiles), dim3(256), lds, b->stream, f);
+        HIPCHK(hipGetLastError());
+        if (last) b->hist_cur ^= 1;
+    } else if (b->fused) {
         // boundary stage-3 outputs + last stage, one workgroup per channel (k_tail4)
         Tail4Args f;
         f.t = t;
