@@ -122,7 +122,7 @@ def flops_per_channel_sample(chain, n_stages):
     return total
 
 
-def profile_facts(n_ch, fused, pair, matrix=False):
+def profile_facts(n_ch, fused, pair, matrix=False, fused3=False):
     """HBM bytes per k_stage12 launch and the clock the chip sustains, from the rocprofv3 --pmc passes of this build
     (tools_pmc.sh -> profiles/*_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     None when no profile of this channel count / kernel path is committed."""
@@ -131,7 +131,7 @@ def profile_facts(n_ch, fused, pair, matrix=False):
         try:
             d = json.load(open(f))
             if (d.get("channels") == n_ch and bool(d.get("fused_tail", False)) == bool(fused) and bool(d.get("pair_lanes", False)) == bool(pair)
-                    and bool(d.get("matrix_pipe", False)) == bool(matrix)):
+                    and bool(d.get("matrix_pipe", False)) == bool(matrix) and bool(d.get("fused3", False)) == bool(fused3)):
                 return d, os.path.basename(f)
         except (OSError, ValueError):
             pass
@@ -535,6 +535,7 @@ def main():
     check["how"] = ("every rank: checksum of each of the ring's blocks as it arrived in the bank's input ring (rank 0's ring -> "
                     "fan-out -> ingest buffer) against the generator's, before the settling steps")
     fused = fused_seen[n_ch]
+    matrix_main, pair_main = matrix_seen[n_ch], pair_seen[n_ch]      # (of THIS run: later runs of other paths overwrite the dictionaries)
 
     extra = {}
     if world == 1 and not args.no_extra_configs and plan.name == "headline":
@@ -545,6 +546,15 @@ def main():
             extra[name] = {"value": len(o) * L * max(10, args.steps) / dte / 1e6, "unit": "Mch-samples/s",
                            "ms_per_step": dte / max(10, args.steps) * 1e3, "realtime_factor": L * max(10, args.steps) / dte / ch.fs,
                            "kernel_ms_avg": {n: v[0] for n, v in ke.items()}, "fused_tail": fused_seen[len(o)]}
+
+    if world == 1 and not args.no_extra_configs and plan.name == "headline" and tuning is None and matrix_main == 1:
+        # the same workload with SDRXGPU_FLAG_FUSED_STAGE3 (k_stage123m + k_tail_c: no stage-2 scratch; opt-in because of its rounding,
+        # include/sdrx_gpu.h)
+        dtb, kb = run(offs, max(30, args.steps), args.warmup, tuning_override={"matrix_pipe": 3})
+        nb_steps = max(30, args.steps)
+        extra["the workload with SDRXGPU_FLAG_FUSED_STAGE3 (stages 2-3 in the stage-1 kernel, no stage-2 scratch; opt-in)"] = {
+            "value": n_ch * L * nb_steps / dtb / 1e6, "unit": "Mch-samples/s", "ms_per_step": dtb / nb_steps * 1e3,
+            "realtime_factor": L * nb_steps / dtb / ch.fs, "kernel_ms_avg": {n: v[0] for n, v in kb.items()}}
 
     if world == 1 and not args.no_extra_configs and plan.name == "headline":
         # BASELINE configs[4], one GPU's share: 2 independent 10 MS/s streams x 1024 channels, each stream's block
@@ -616,26 +626,32 @@ def main():
         bpu = algorithmic_bytes_per_channel_sample(ch.m_total)
         k12_ms, k12_n = k["k_stage12"]
         units = float(n_ch) * L                                   # channel-samples per launch
-        f12 = flops_per_channel_sample(ch, 3 if fused else 2)     # what k_stage12 computes per channel-sample
+        fused3 = matrix_main == 2                           # k_stage123m: stages 1-3 in the dominant kernel, k_tail_c behind it
+        f12 = flops_per_channel_sample(ch, 3 if (fused or fused3) else 2)     # what the dominant kernel computes per channel-sample
         f_all = flops_per_channel_sample(ch, len(ch.stages))
         ach_tf = f12 * units / (k12_ms / 1e3) / 1e12 if k12_n else None
-        matrix = bool(matrix_seen[n_ch])
-        prof, prof_src = profile_facts(n_ch, fused, pair_seen[n_ch], matrix)
+        matrix = bool(matrix_main)
+        prof, prof_src = profile_facts(n_ch, fused, pair_main, matrix, fused3)
         n_y2, n_y3 = L // (ch.stages[0].m * ch.stages[1].m), L // (ch.stages[0].m * ch.stages[1].m * ch.stages[2].m)
-        if fused:     # k_tail4: [hist3 | y3] + the range-boundary buffer in, decimated IQ out (k_agc reads the caller's rows)
+        if fused3:    # k_tail_c: the stage-3 entries k_stage123m left (16 of 8 bytes per segment of 240 stage-1 outputs) in, decimated IQ out
+            tail_bytes = n_ch * (8.0 * 16 * ((L // ch.stages[0].m + 239) // 240) + 8.0 * 512)
+        elif fused:   # k_tail4: [hist3 | y3] + the range-boundary buffer in, decimated IQ out (k_agc reads the caller's rows)
             tail_bytes = n_ch * (8.0 * (n_y3 + 80) + 8.0 * 40 * ((n_y2 + 767) // 768) + 8.0 * 512)
         else:         # k_tail_s: the stage-2 scratch in, decimated IQ out
             tail_bytes = n_ch * (8.0 * n_y2 + 8.0 * 512)
         kern = {
             "k_stage12": {"ms": k12_ms, "bound": "mfma" if matrix else "valu_fp32", "flops_per_unit": f12, "achieved_tflops": ach_tf,
                           "frac": ach_tf / FP32_PEAK_TF if ach_tf else None,
-                          "does": ("k_stage12m: mixer + stage 1 as f32 MFMAs (16x16x4, conjugate pairs share four real products), "
+                          "does": ("k_stage123m: mixer + stage 1 as f32 MFMAs (16x16x4, conjugate pairs share four real products), stages 2-3 as "
+                                   "one 119-tap transposed filter on the vector ALU, no stage-2 scratch" if fused3 else
+                                   "k_stage12m: mixer + stage 1 as f32 MFMAs (16x16x4, conjugate pairs share four real products), "
                                    "stage 2 on the vector ALU" if matrix else
                                    "mixer + stages 1-2" + (" + stage 3 of the workgroup's own range (fused)" if fused else ""))},
             "k_tail": {"ms": k["k_tail"][0], "bound": "hbm", "algorithmic_bytes": tail_bytes,
                        "achieved_gbs": tail_bytes / (k["k_tail"][0] / 1e3) / 1e9 if k["k_tail"][1] else None,
                        "frac": tail_bytes / (k["k_tail"][0] / 1e3) / 1e9 / HBM_PEAK_GBS if k["k_tail"][1] else None,
-                       "does": "k_tail4: range-boundary stage-3 outputs + stage 4" if fused else "k_tail_s: stages 3-4 from the stage-2 scratch"},
+                       "does": ("k_tail_c: stage-3 outputs put together from k_stage123m's entries + stage 4" if fused3 else
+                                "k_tail4: range-boundary stage-3 outputs + stage 4" if fused else "k_tail_s: stages 3-4 from the stage-2 scratch")},
             "k_agc": {"ms": k["k_agc"][0], "bound": "latency (512 dependent steps per channel)",
                       "ns_per_step": k["k_agc"][0] * 1e6 / 512 if k["k_agc"][1] else None},
         }
@@ -655,10 +671,11 @@ def main():
                 "parallelism": plan.parallelism +
                                (", block k+1 broadcast over xGMI into the banks' other input ring while block k is processed"
                                 if (world > 1 or args.force_dist) else ""),
-                "kernel_path": ("stage 3 fused behind stages 1-2 (k_stage12 + k_tail4 + k_agc)" if fused else
-                                "separate tail (k_stage12 + k_tail_s + k_agc)") +
-                               (f"; two channels per lane in k_stage12, {pair_seen[n_ch] - 1} conjugate pairs share the mixer" if pair_seen[n_ch] else "") +
-                               ("; mixer + stage 1 on the f32 matrix pipe (k_stage12m)" if matrix_seen[n_ch] else ""),
+                "kernel_path": ("mixer + stage 1 on the f32 matrix pipe, stages 2-3 in the same kernel, no stage-2 scratch (k_stage123m + k_tail_c + k_agc)" if fused3 else
+                                ("stage 3 fused behind stages 1-2 (k_stage12 + k_tail4 + k_agc)" if fused else
+                                 "separate tail (k_stage12 + k_tail_s + k_agc)") +
+                                (f"; two channels per lane in k_stage12, {pair_main - 1} conjugate pairs share the mixer" if pair_main else "") +
+                                ("; mixer + stage 1 on the f32 matrix pipe (k_stage12m)" if matrix_main else "")),
                 "realtime_factor": value * 1e6 / (n_ch * world * ch.fs),
                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),   # (set before the HIP runtime started: two banks' streams need queues of their own)
                 "settle_steps": SETTLE_STEPS,    # untimed, before the W warm-up steps (clock settling, see time_bank)
@@ -671,7 +688,7 @@ def main():
                 # duration (HIP events on the bank's stream, inside the timed region)
                 # matrix path: the f32 MFMA and the vector ALU share the FP32 datapath (measured additive): one
                 # ceiling of 157.3 TFLOP/s for both, the dense f32 MFMA peak of MI355X_MICROARCH.md
-                "bound": "mfma" if matrix else "valu_fp32", "kernel": "k_stage12m" if matrix else "k_stage12",
+                "bound": "mfma" if matrix else "valu_fp32", "kernel": "k_stage123m" if fused3 else "k_stage12m" if matrix else "k_stage12",
                 "achieved": ach_tf, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": ach_tf / FP32_PEAK_TF if ach_tf else None,
                 "flops_per_unit": f12, "flops_per_unit_whole_step": f_all,

@@ -59,6 +59,16 @@ extern "C" {
                                             sdrxgpu_bank_flush returns the last block.  Same outputs, bit for bit.
                                             Measured: no faster than the default serial order. */
 
+#define SDRXGPU_FLAG_FUSED_STAGE3   0x8u  /* large banks of the 10 MS/s chain (where the mixer + stage 1 run on the f32 matrix pipe): run
+                                            decimator stages 2 and 3 in that kernel too, as one 119-tap filter, and keep no stage-2
+                                            scratch (k_stage123m + k_tail_c): 11 % less time per block, 2.5 GB -> 1.0 GB of HBM traffic.
+                                            The price is rounding: a chain of 119 fp32 products rounds relative to partial sums that
+                                            carry every signal still in band after stage 1, so on a channel NEXT to a strong carrier
+                                            this path is 2 to 3 x the reference's own Release-vs-portable deviation away from the
+                                            reference where the default path is 1.1 to 1.4 x (within 1e-5 under a carrier of 0.3 of full
+                                            scale over a floor of 0.25, beyond it under one of 0.6; profiles/r04_parity_margins.json),
+                                            and a different cut of the stream into calls changes the last bits.  Off by default. */
+
 typedef struct sdrxgpu_bank sdrxgpu_bank;
 
 /* std::complex<float> / iqsample_t */
@@ -104,7 +114,9 @@ typedef struct {
                                 0 = auto, 1 = never, 2 = require                                              */
     uint32_t matrix_pipe;    /* mixer + stage 1 of the 10 MS/s chain on the f32 matrix pipe (k_stage12m: exact fp32
                                 fma chains in another summation order -- the one choice here whose outputs differ
-                                from the others', by rounding only): 0 = auto, 1 = never, 2 = require            */
+                                from the others', by rounding only): 0 = auto (from 3 584 channels; with
+                                SDRXGPU_FLAG_FUSED_STAGE3: k_stage123m), 1 = never, 2 = require k_stage12m,
+                                3 = require k_stage123m (stages 2-3 in the same kernel)                          */
     uint32_t m_slot_groups;  /* k_stage12m workgroup = m_slot_groups x m_seg_groups tiles (waves) of 16 channel    */
     uint32_t m_seg_groups;   /*   pairs x 16 time segments: (2,2), (4,2) or (2,4); 0 = auto                        */
 } sdrxgpu_tuning;
@@ -174,7 +186,7 @@ typedef struct {
     uint32_t k12_waves;        /* geometry of the stage-1/2 launch as chosen (or forced by tuning): waves per workgroup, */
     uint32_t k12_cpw;          /*   channels (slots) per wave, */
     uint32_t k12_bodies;       /*   bodies per lane */
-    uint32_t matrix_pipe;      /* 1: mixer + stage 1 run on the f32 matrix pipe (k_stage12m) */
+    uint32_t matrix_pipe;      /* 1: mixer + stage 1 run on the f32 matrix pipe (k_stage12m); 2: and stages 2-3 in the same kernel (k_stage123m) */
     uint32_t m_slots;          /*   its channel-pair slots (pairs + channels without partner + padding) */
 } sdrxgpu_bank_info;
 

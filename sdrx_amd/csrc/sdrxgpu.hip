@@ -828,7 +828,9 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe = 2 / 3 goes with neither fused_tail = 2, pair_lanes = 2 nor k12_waves / k12_cpw");
         }
         b->mfma = can && (tune0.matrix_pipe >= 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 3584));
-        b->mfma3 = b->mfma && can3 && (tune0.matrix_pipe == 3 || tune0.matrix_pipe == 0);
+        // (never automatic: 11 % faster per block, but 2 to 3 x the reference's own build-to-build rounding spread on channels next
+        // to a strong carrier, where k_stage12m is at 1.1 to 1.4 x: DESIGN.md 4.9 -- a caller's choice, SDRXGPU_FLAG_FUSED_STAGE3)
+        b->mfma3 = b->mfma && can3 && (tune0.matrix_pipe == 3 || (tune0.matrix_pipe == 0 && (cfg->flags & SDRXGPU_FLAG_FUSED_STAGE3)));
         if (b->mfma) {
             b->mGS = tune0.m_slot_groups ? (int)tune0.m_slot_groups : 2;
             b->mGT = tune0.m_seg_groups ? (int)tune0.m_seg_groups : 2;

@@ -128,14 +128,14 @@ def test_a_channels_bits_do_not_depend_on_who_else_is_in_the_bank():
 
 
 @pytest.mark.parametrize("n_ch", [3584, 10000])
-def test_large_bank_by_default_host_parts_and_oracle(oracle, n_ch):
-    """The default path from 3 584 channels (the measured crossover) on; 10 000 = the bench workload, four host parts."""
+def test_large_bank_host_parts_and_oracle(oracle, n_ch):
+    """k_stage12m + k_tail_s at the sizes it was the default for in round 3; 10 000 = the bench workload, four host parts."""
     ch = chains.chain("10")
     offs = chains.offsets_cycled(n_ch, ch.N)
     tabs = sb.translators_for(ch, offs)
     L = ch.block_len
     blocks = [synth.synth_iq(9, b * L, L, 0.25, [tabs[650]], [0.2], ch.N, 10000) for b in range(2)]
-    bank = sb.ChannelBank(tabs, ch.stage_tuples())
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": REQ})     # (the default of such a bank is k_stage123m: test_gpu_fused3.py)
     info = bank.info()
     assert info.matrix_pipe == 1
     outs = [bank.process(x) for x in blocks]                # host entry: channel parts, D2H beside the kernels

@@ -66,7 +66,8 @@ if "k_stage12" in out:
 if b3:
     out["fused_tail"] = "fused" in b3["config"]["kernel_path"].split("(")[0]
     out["pair_lanes"] = "two channels per lane" in b3["config"]["kernel_path"]
-    out["matrix_pipe"] = "k_stage12m" in b3["config"]["kernel_path"]
+    out["matrix_pipe"] = "matrix pipe" in b3["config"]["kernel_path"]
+    out["fused3"] = "k_stage123m" in b3["config"]["kernel_path"]
 json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
