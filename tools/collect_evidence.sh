@@ -8,14 +8,17 @@ set -u
 cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=8      # (what bench.py sets for itself; under rocprofv3 the runtime starts before the program does)
 E=gpurun_out/ev; rm -rf $E; mkdir -p $E
-rm -f gpurun_out/parity_margins.jsonl
+rm -f gpurun_out/parity_margins.jsonl gpurun_out/r04_parity_pairs.jsonl
 step() { tools/run_gpu_step.sh "$@" || exit 1; }
 step 900 $E/gpu_tests.log python -m pytest tests -m gpu -q
-cp gpurun_out/parity_margins.jsonl $E/ 2>/dev/null
+cp gpurun_out/parity_margins.jsonl gpurun_out/r04_parity_pairs.jsonl $E/ 2>/dev/null
 step 400 $E/bench.log python bench.py
 step 200 $E/bench_vector.log python bench.py --matrix 1 --no-cpu-baseline --no-extra-configs
 step 200 $E/bench_vector_separate_tail.log python bench.py --matrix 1 --fused 1 --no-cpu-baseline --no-extra-configs
 step 200 $E/bench_rccl_1rank.log python bench.py --force-dist --no-cpu-baseline --no-extra-configs
+step 200 $E/bench_fused3.log python bench.py --matrix 3 --no-cpu-baseline --no-extra-configs
+step 200 $E/bench_c4.log python bench.py --config c4 --steps 300 --no-cpu-baseline
+step 200 $E/bench_c5.log python bench.py --config c5 --steps 300 --no-cpu-baseline
 step 60 $E/ubench_valu.txt tools/ubench_valu.bin
 step 60 $E/ubench_hbm_read.txt tools/ubench_hbm_read.bin
 step 120 $E/ubench_mfma_fir.txt tools/ubench_mfma_fir.bin
@@ -29,11 +32,14 @@ prof() {    # prof <name> <bench args...>
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "rocprofv3 run killed at its time limit: stopping"; exit 99; fi
 }
 prof trace
+python3 tools/trace_outliers.py $E/trace > $E/trace_outliers.txt 2>&1
+prof trace_fused3 --matrix 3
 prof trace_vector --matrix 1
 ./tools_pmc.sh ev/pmc_matrix > $E/pmc_matrix.log 2>&1 || exit 1
+./tools_pmc.sh ev/pmc_fused3 --matrix 3 > $E/pmc_fused3.log 2>&1 || exit 1
 ./tools_pmc.sh ev/pmc_vector --matrix 1 > $E/pmc_vector.log 2>&1 || exit 1
 find $E -name "*kernel_stats.csv" | head
 # keep the merge small: drop the raw traces, keep the stats
-find $E/trace $E/trace_vector -type f ! -name "*stats*" -delete 2>/dev/null
+find $E/trace $E/trace_vector $E/trace_fused3 -type f ! -name "*stats*" -delete 2>/dev/null
 find $E -name "*counter_collection.csv" -delete; find $E -name "*agent_info.csv" -delete
 du -sh $E
