@@ -116,7 +116,10 @@ typedef struct {
                                 fma chains in another summation order -- the one choice here whose outputs differ
                                 from the others', by rounding only): 0 = auto (from 3 584 channels; with
                                 SDRXGPU_FLAG_FUSED_STAGE3: k_stage123m), 1 = never, 2 = require k_stage12m,
-                                3 = require k_stage123m (stages 2-3 in the same kernel)                          */
+                                3 = require k_stage123m (stages 2-3 in the same kernel).  Because the automatic
+                                choice depends on the bank's size, a channel's last bits depend on it too -- and so on
+                                how a channel list is sharded over GPUs (<= the tolerances of INTEGRATION.md 6): pin this
+                                field where bit-identical results across layouts matter                          */
     uint32_t m_slot_groups;  /* k_stage12m workgroup = m_slot_groups x m_seg_groups tiles (waves) of 16 channel    */
     uint32_t m_seg_groups;   /*   pairs x 16 time segments: (2,2), (4,2) or (2,4); 0 = auto                        */
 } sdrxgpu_tuning;
