@@ -65,8 +65,8 @@ extern "C" {
                                             The price is rounding: a chain of 119 fp32 products rounds relative to partial sums that
                                             carry every signal still in band after stage 1, so on a channel NEXT to a strong carrier
                                             this path is 2 to 3 x the reference's own Release-vs-portable deviation away from the
-                                            reference where the default path is 1.1 to 1.4 x (within 1e-5 under a carrier of 0.3 of full
-                                            scale over a floor of 0.25, beyond it under one of 0.6; profiles/r04_parity_margins.json),
+                                            reference where the default path is 1.1 to 1.4 x (at the edge of 1e-5 under a carrier of 0.3 of
+                                            full scale over a floor of 0.25, beyond it under one of 0.6; profiles/r04_b_parity_pairs.jsonl),
                                             and a different cut of the stream into calls changes the last bits.  Off by default. */
 
 typedef struct sdrxgpu_bank sdrxgpu_bank;
