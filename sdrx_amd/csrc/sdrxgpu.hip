@@ -1851,7 +1851,6 @@ static int launch_stage123(sdrxgpu_bank *b, size_t in_len, hipStream_t st, sdrxg
         for (int i = 0; i < (t.tB + 1) / 2; i++) t.hB[i] = b->taps[3][i];
         t.n_b = (int)(n1 / b->m_total - n0 / b->m_total);
         if (t.n_b > b->keep_stride) return fail(SDRXGPU_ERR_HIP, "internal: %d outputs > keep_stride %d", t.n_b, b->keep_stride);
-        if (job->n_out3 + b->H3c + 2 > 8000) return fail(SDRXGPU_ERR_HIP, "internal: %d stage-3 outputs exceed k_tail_c's LDS row", job->n_out3);
         job->valid = true;
     }
     {
