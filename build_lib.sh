@@ -4,6 +4,7 @@
 set -e
 cd "$(dirname "$0")"
 mkdir -p sdrx_amd/lib
+# (-Wno-int-to-pointer-cast: LDS addresses are 32-bit on the device; the host pass of the same header sees 64-bit pointers)
 # (-Wno-pass-failed: the occupancy *target* of __launch_bounds__ is a register cap here; LDS decides occupancy)
-FLAGS="-Wno-pass-failed -Wno-int-to-void-pointer-cast -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fno-slp-vectorize"
+FLAGS="-Wno-pass-failed -Wno-int-to-void-pointer-cast -Wno-int-to-pointer-cast -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $FLAGS "$@" -o sdrx_amd/lib/libsdrxgpu.so sdrx_amd/csrc/sdrxgpu.hip
