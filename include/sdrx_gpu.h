@@ -114,12 +114,14 @@ typedef struct {
                                 0 = auto, 1 = never, 2 = require                                              */
     uint32_t matrix_pipe;    /* mixer + stage 1 of the 10 MS/s chain on the f32 matrix pipe (k_stage12m: exact fp32
                                 fma chains in another summation order -- the one choice here whose outputs differ
-                                from the others', by rounding only): 0 = auto (from 3 584 channels; with
+                                from the others', by rounding only): 0 = auto (banks of 2 048 channels or more whose
+                                channels mostly come in +k / -k pairs: the kernel's work goes with pairs + unpaired
+                                channels, and bank_create compares the two kernels' launch counts; with
                                 SDRXGPU_FLAG_FUSED_STAGE3: k_stage123m), 1 = never, 2 = require k_stage12m,
                                 3 = require k_stage123m (stages 2-3 in the same kernel).  Because the automatic
-                                choice depends on the bank's size, a channel's last bits depend on it too -- and so on
-                                how a channel list is sharded over GPUs (<= the tolerances of INTEGRATION.md 6): pin this
-                                field where bit-identical results across layouts matter                          */
+                                choice depends on the bank's channel list, a channel's last bits depend on it too -- and
+                                so on how a channel list is sharded over GPUs (<= the tolerances of INTEGRATION.md 6): pin
+                                this field where bit-identical results across layouts matter                     */
     uint32_t m_slot_groups;  /* k_stage12m workgroup = m_slot_groups x m_seg_groups tiles (waves) of 16 channel    */
     uint32_t m_seg_groups;   /*   pairs x 16 time segments: (2,2), (4,2) or (2,4); 0 = auto                        */
 } sdrxgpu_tuning;

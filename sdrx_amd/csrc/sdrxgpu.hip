@@ -827,7 +827,9 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             free_bank(b);
             return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe = 2 / 3 goes with neither fused_tail = 2, pair_lanes = 2 nor k12_waves / k12_cpw");
         }
-        b->mfma = can && (tune0.matrix_pipe >= 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 3584));
+        // automatic: from 2 048 channels, if enough of them have their conjugate partner in the bank (decided below, once the
+        // partners are known)
+        b->mfma = can && (tune0.matrix_pipe >= 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 2048));
         // (never automatic: 11 % faster per block, but 2 to 3 x the reference's own build-to-build rounding spread on channels next
         // to a strong carrier, where k_stage12m is at 1.1 to 1.4 x: DESIGN.md 4.9 -- a caller's choice, SDRXGPU_FLAG_FUSED_STAGE3)
         b->mfma3 = b->mfma && can3 && (tune0.matrix_pipe == 3 || (tune0.matrix_pipe == 0 && (cfg->flags & SDRXGPU_FLAG_FUSED_STAGE3)));
@@ -855,6 +857,89 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         }
         b->mfma = b->mfma3 = false;                             // automatic choice: the vector kernels
         b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
+    }
+
+    // Slots of k_stage12m: a channel and the channel whose table is its exact complex conjugate (+k / -k steps from the
+    // tuner); whoever finds no partner gets a slot of its own (the kernel computes the pair all the same and drops the
+    // second half: a channel's bits do not depend on who else is in the bank).  The whole-bank list is made here, ahead of the
+    // launch geometry: how many workgroups a launch has depends on how many channels found a partner, not on how many there are.
+    std::vector<std::string> m_keys, m_fkeys;
+    std::vector<int2> m_slots_all;
+    int m_np_all = 0;
+    const int m_set = 16 * std::max(1, b->mGS);
+    auto m_pair_range = [&](int c_lo, int c_hi, std::vector<int2> &slots, int &n_pairs) {
+        std::unordered_map<std::string, std::vector<int>> open;
+        std::vector<int2> conj;
+        std::vector<int> single;
+        for (int c = c_lo; c < c_hi; c++) {
+            auto it = open.find(m_fkeys[c]);
+            if (it != open.end() && !it->second.empty()) {
+                conj.push_back(make_int2(it->second.back(), c));
+                it->second.pop_back();
+            } else {
+                open[m_keys[c]].push_back(c);
+            }
+        }
+        for (auto &kv : open)
+            for (int c : kv.second) single.push_back(c);
+        std::sort(single.begin(), single.end());
+        std::sort(conj.begin(), conj.end(), [](const int2 &u, const int2 &v) { return u.x < v.x; });
+        n_pairs += (int)conj.size();
+        slots.insert(slots.end(), conj.begin(), conj.end());
+        for (int c : single) slots.push_back(make_int2(c, -1));
+        while (slots.size() % m_set) slots.push_back(make_int2(-1, -1));
+    };
+    if (b->mfma) {
+        auto key_of = [&](uint32_t c, bool flip) {
+            const sdrxgpu_channel &ch = cfg->channels[c];
+            if (ch.n_translator == 0) return std::string("unit");         // no translator = the unit table, its own conjugate
+            std::string k((const char *)ch.translator, (size_t)ch.n_translator * sizeof(sdrxgpu_iq));
+            if (flip)
+                for (size_t i = 0; i < ch.n_translator; i++) k[i * 8 + 7] ^= (char)0x80;   // sign bit of .im
+            return k;
+        };
+        m_keys.resize(b->n_ch);
+        m_fkeys.resize(b->n_ch);
+        for (uint32_t c = 0; c < b->n_ch; c++) {
+            m_keys[c] = key_of(c, false);
+            m_fkeys[c] = key_of(c, true);
+        }
+        m_pair_range(0, (int)b->n_ch, m_slots_all, m_np_all);
+        // Automatic choice: the kernel's work goes with its SLOTS (a channel without partner costs what a pair costs), and what a
+        // launch costs is rounds of workgroup places x bodies per lane for either kernel -- the same count the geometry below
+        // uses to pick the lane length, in units of one body of a workgroup that shares its CU: 15.0 us for k_stage12m (64 channel
+        // places x 32 segments), 5.6 us for k_stage12p (32 channels x 16 segments).  Measured on bench.py's channel list (whole
+        // cycles of the 1 200 offsets are pairs, the rest mostly single: 0.50 - 0.67 slots per channel), stage-1/2 kernel ms,
+        // matrix / vector, and the ratio the counts predict: 2 048 channels 0.164 / 0.177 (0.92; 0.94), 2 304: 0.164 / 0.185 (0.89;
+        // 0.89), 2 560: 0.197 / 0.218 (0.91; 0.89), 2 816: 0.198 / 0.224 (0.89; 0.89), 3 072: 0.253 / 0.257 (0.98; 1.05),
+        // 3 328: 0.252 / 0.260 (0.97; 1.03), 3 584: 0.252 / 0.284 (0.89; 0.93), 4 096: 0.293 / 0.324 (0.90; 0.89), 10 000:
+        // 0.579 / 0.77 (0.75; 0.76).  Below 2 048 channels neither count is that good (few workgroups, uneven XCDs; 1 024: 1.14
+        // against a predicted 0.96): the vector kernels stay.  Automatic = predicted ratio under 0.97.
+        if (tune0.matrix_pipe == 0) {
+            const long long max_chunk = cfg->max_in_len ? cfg->max_in_len : 512LL * b->m_total;
+            const long long U = (max_chunk / b->MM + 1 + k12->Y2B - 1) / k12->Y2B;
+            const long long places = 2LL * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+            auto launch_cost = [&](long long wgs_whole_segments) {            // min over lane lengths of rounds x (warm-up + bodies)
+                double best = -1.0;
+                for (int nb = b->bps; nb >= 1; nb--) {
+                    if (b->bps % nb) continue;
+                    const long long wgs = wgs_whole_segments * (b->bps / nb);
+                    const long long full = wgs / places, rem = wgs % places;
+                    const double rounds = (double)full + (rem == 0 ? 0.0 : (2 * rem <= places ? 0.61 : 1.0));
+                    const double cost = rounds * (b->WU + nb);
+                    if (best < 0 || cost < best) best = cost;
+                }
+                return best;
+            };
+            const long long g16 = (U + 16LL * b->bps - 1) / (16LL * b->bps);                        // segment groups of 16
+            const double cost_m = launch_cost((long long)(m_slots_all.size() / m_set) * ((g16 + b->mGT - 1) / b->mGT));
+            const double cost_v = launch_cost(((long long)b->n_ch + 2 * kPairSlots - 1) / (2 * kPairSlots) * g16);
+            if (15.0 * cost_m >= 0.97 * 5.6 * cost_v) {
+                b->mfma = b->mfma3 = false;
+                b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
+                m_slots_all.clear();
+            }
+        }
     }
 
     // tail-stage history: stage-2 outputs the remaining stages still need from earlier calls
@@ -1003,7 +1088,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         if (b->mfma) {
             // workgroups of mGS x mGT tiles, two (256 threads) or one (512) per CU; same count of rounds x bodies as above
             const long long Gs = (U + 16LL * b->bps - 1) / (16LL * b->bps);
-            const long long sets = ((long long)b->n_ch / 2 + 16 * b->mGS - 1) / (16 * b->mGS) + 1;
+            const long long sets = (long long)m_slots_all.size() / m_set;      // (exact: partners found, not channels / 2)
             const long long slots = (long long)n_cu * std::max<long long>(1, (long long)(160 * 1024 / k12m_lds_bytes(b->mGS, b->mGT)));
             double best_cost = -1.0;
             for (int nb = b->bps; nb >= 1; nb--) {
@@ -1157,53 +1242,17 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     }
 
     if (b->mfma) {
-        // Slots of k_stage12m: a channel and the channel whose table is its exact complex conjugate (+k / -k steps from the
-        // tuner); whoever finds no partner gets a slot of its own (the kernel computes the pair all the same and drops the
-        // second half: a channel's bits do not depend on who else is in the bank).  Two lists: partners looked for in the
-        // whole bank (launches that cover every channel: the device and pinned entries), and inside each host part
-        // (sdrxgpu_bank_process runs the parts one after the other, every kernel on one part's channels).
-        const int set = 16 * b->mGS;
-        auto key_of = [&](uint32_t c, bool flip) {
-            const sdrxgpu_channel &ch = cfg->channels[c];
-            if (ch.n_translator == 0) return std::string("unit");         // no translator = the unit table, its own conjugate
-            std::string k((const char *)ch.translator, (size_t)ch.n_translator * sizeof(sdrxgpu_iq));
-            if (flip)
-                for (size_t i = 0; i < ch.n_translator; i++) k[i * 8 + 7] ^= (char)0x80;   // sign bit of .im
-            return k;
-        };
-        std::vector<std::string> keys(b->n_ch), fkeys(b->n_ch);
-        for (uint32_t c = 0; c < b->n_ch; c++) {
-            keys[c] = key_of(c, false);
-            fkeys[c] = key_of(c, true);
-        }
-        auto pair_range = [&](int c_lo, int c_hi, std::vector<int2> &slots, int &n_pairs) {
-            std::unordered_map<std::string, std::vector<int>> open;
-            std::vector<int2> conj;
-            std::vector<int> single;
-            for (int c = c_lo; c < c_hi; c++) {
-                auto it = open.find(fkeys[c]);
-                if (it != open.end() && !it->second.empty()) {
-                    conj.push_back(make_int2(it->second.back(), c));
-                    it->second.pop_back();
-                } else {
-                    open[keys[c]].push_back(c);
-                }
-            }
-            for (auto &kv : open)
-                for (int c : kv.second) single.push_back(c);
-            std::sort(single.begin(), single.end());
-            std::sort(conj.begin(), conj.end(), [](const int2 &u, const int2 &v) { return u.x < v.x; });
-            n_pairs += (int)conj.size();
-            slots.insert(slots.end(), conj.begin(), conj.end());
-            for (int c : single) slots.push_back(make_int2(c, -1));
-            while (slots.size() % set) slots.push_back(make_int2(-1, -1));
-        };
-        std::vector<int2> slots_all, slots_parts;
-        int np_all = 0, np_parts = 0;
-        pair_range(0, (int)b->n_ch, slots_all, np_all);
+        // Two slot lists: partners looked for in the whole bank (above; launches that cover every channel: the device and pinned
+        // entries), and inside each host part (sdrxgpu_bank_process runs the parts one after the other, every kernel on one
+        // part's channels).
+        const int set = m_set;
+        std::vector<int2> &slots_all = m_slots_all;
+        std::vector<int2> slots_parts;
+        const int np_all = m_np_all;
+        int np_parts = 0;
         b->part_gm.assign(1, 0);
         for (size_t p = 0; p + 1 < b->part_ch.size(); p++) {
-            pair_range(b->part_ch[p], b->part_ch[p + 1], slots_parts, np_parts);
+            m_pair_range(b->part_ch[p], b->part_ch[p + 1], slots_parts, np_parts);
             b->part_gm.push_back((int)(slots_parts.size() / set));
         }
         b->n_pairs_m = np_all;

@@ -127,6 +127,22 @@ def test_a_channels_bits_do_not_depend_on_who_else_is_in_the_bank():
     assert np.array_equal(alone[1].view(np.uint32), swapped[0].view(np.uint32))
 
 
+def test_automatic_choice_goes_with_the_partners_found_not_with_the_channel_count():
+    # k_stage12m's work goes with its slots: a channel without its conjugate partner costs what a pair costs.  The automatic
+    # choice (bank_create: the two kernels' launch counts) takes the matrix pipe for a bank whose channels mostly come in +k / -k
+    # pairs and the vector kernels for one of the same size without any; below 2 048 channels always the vector kernels.
+    ch = chains.chain("10")
+    want = {}
+    for name, offs in (("paired_2400", chains.offsets_cycled(2400, ch.N)),
+                       ("one_sided_2400", [1 + (i % 599) for i in range(2400)]),
+                       ("paired_1800", [(-1) ** i * (1 + (i // 2) % 599) for i in range(1800)]),
+                       ("one_sided_6000", [1 + (i % 599) for i in range(6000)])):
+        bank = sb.ChannelBank(sb.translators_for(ch, offs), ch.stage_tuples())
+        want[name] = int(bank.info().matrix_pipe)
+        bank.close()
+    assert want == {"paired_2400": 1, "one_sided_2400": 0, "paired_1800": 0, "one_sided_6000": 0}
+
+
 @pytest.mark.parametrize("n_ch", [3584, 10000])
 def test_large_bank_host_parts_and_oracle(oracle, n_ch):
     """k_stage12m + k_tail_s at the sizes it was the default for in round 3; 10 000 = the bench workload, four host parts."""
