@@ -114,7 +114,7 @@ typedef struct {
                                 0 = auto, 1 = never, 2 = require                                              */
     uint32_t matrix_pipe;    /* mixer + stage 1 of the 10 MS/s chain on the f32 matrix pipe (k_stage12m: exact fp32
                                 fma chains in another summation order -- the one choice here whose outputs differ
-                                from the others', by rounding only): 0 = auto (banks of 2 048 channels or more whose
+                                from the others', by rounding only): 0 = auto (banks of 1 024 channels or more whose
                                 channels mostly come in +k / -k pairs: the kernel's work goes with pairs + unpaired
                                 channels, and bank_create compares the two kernels' launch counts; with
                                 SDRXGPU_FLAG_FUSED_STAGE3: k_stage123m), 1 = never, 2 = require k_stage12m,

@@ -827,9 +827,9 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
             free_bank(b);
             return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.matrix_pipe = 2 / 3 goes with neither fused_tail = 2, pair_lanes = 2 nor k12_waves / k12_cpw");
         }
-        // automatic: from 2 048 channels, if enough of them have their conjugate partner in the bank (decided below, once the
-        // partners are known)
-        b->mfma = can && (tune0.matrix_pipe >= 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 2048));
+        // automatic: from 1 024 channels (where the vector path is k_stage12p), if enough of them have their conjugate partner in
+        // the bank (decided below, once the partners are known)
+        b->mfma = can && (tune0.matrix_pipe >= 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 1024));
         // (never automatic: 11 % faster per block, but 2 to 3 x the reference's own build-to-build rounding spread on channels next
         // to a strong carrier, where k_stage12m is at 1.1 to 1.4 x: DESIGN.md 4.9 -- a caller's choice, SDRXGPU_FLAG_FUSED_STAGE3)
         b->mfma3 = b->mfma && can3 && (tune0.matrix_pipe == 3 || (tune0.matrix_pipe == 0 && (cfg->flags & SDRXGPU_FLAG_FUSED_STAGE3)));
@@ -913,8 +913,10 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         // matrix / vector, and the ratio the counts predict: 2 048 channels 0.164 / 0.177 (0.92; 0.94), 2 304: 0.164 / 0.185 (0.89;
         // 0.89), 2 560: 0.197 / 0.218 (0.91; 0.89), 2 816: 0.198 / 0.224 (0.89; 0.89), 3 072: 0.253 / 0.257 (0.98; 1.05),
         // 3 328: 0.252 / 0.260 (0.97; 1.03), 3 584: 0.252 / 0.284 (0.89; 0.93), 4 096: 0.293 / 0.324 (0.90; 0.89), 10 000:
-        // 0.579 / 0.77 (0.75; 0.76).  Below 2 048 channels neither count is that good (few workgroups, uneven XCDs; 1 024: 1.14
-        // against a predicted 0.96): the vector kernels stay.  Automatic = predicted ratio under 0.97.
+        // 0.579 / 0.77 (0.75; 0.76); smaller banks (since k_stage12m deals its units evenly to the XCDs): 1 024: 0.097 / 0.100
+        // (0.97; 0.96), 1 152: 0.098 / 0.118 (0.83; 0.94), 1 408: 0.108 / 0.145 (0.75; 0.90), 1 536: 0.148 / 0.139 (1.07; 1.07),
+        // 1 792: 0.162 / 0.152 (1.07; 1.16), 896: 0.097 / 0.095 (1.02; 1.33) -- where the prediction is under 0.97 the matrix
+        // pipe was ahead at every size measured (profiles/r04_lab_matrix_pipe_choice.txt).  Automatic = predicted ratio under 0.97.
         if (tune0.matrix_pipe == 0) {
             const long long max_chunk = cfg->max_in_len ? cfg->max_in_len : 512LL * b->m_total;
             const long long U = (max_chunk / b->MM + 1 + k12->Y2B - 1) / k12->Y2B;
@@ -1742,10 +1744,11 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
         M.L.args.n_wt = (Gs + b->mGT - 1) / b->mGT * b->P;              // time-waves of mGT segment groups
         M.L.args.cg0 = g_lo;
         M.L.args.n_chgroups = g_hi;
-        M.L.args.n_cgx = (g_hi - g_lo + 7) / 8 * 8;
         // (the kernel walks items blockIdx.x, + gridDim.x, ...: a grid capped at the workgroups the chip holds at once makes it
         // persistent -- measured 3 % slower than one workgroup per item, which lets the dispatcher even out the last round)
-        M.L.grid = M.L.args.n_cgx * M.L.args.n_wt;
+        // items = 8 x the units of the XCD that has most (kernels_mfma.hpp: eight equal runs of the sets x time-waves units)
+        M.L.grid = (int)(((long long)(g_hi - g_lo) * M.L.args.n_wt + 7) / 8 * 8);
+        M.L.args.n_cgx = M.L.grid / 8;                          // (k_stage12m reads it as units per XCD)
         M.pa.slots = whole ? b->d_slots_m : b->d_slots_mp;
         M.pa.group_conj = nullptr;
         M.pa.n_slots = whole ? b->n_slots_m : b->n_slots_mp;

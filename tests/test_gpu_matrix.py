@@ -130,17 +130,19 @@ def test_a_channels_bits_do_not_depend_on_who_else_is_in_the_bank():
 def test_automatic_choice_goes_with_the_partners_found_not_with_the_channel_count():
     # k_stage12m's work goes with its slots: a channel without its conjugate partner costs what a pair costs.  The automatic
     # choice (bank_create: the two kernels' launch counts) takes the matrix pipe for a bank whose channels mostly come in +k / -k
-    # pairs and the vector kernels for one of the same size without any; below 2 048 channels always the vector kernels.
+    # pairs and the vector kernels for one of the same size without any; below 1 024 channels always the vector kernels.
     ch = chains.chain("10")
     want = {}
     for name, offs in (("paired_2400", chains.offsets_cycled(2400, ch.N)),
                        ("one_sided_2400", [1 + (i % 599) for i in range(2400)]),
-                       ("paired_1800", [(-1) ** i * (1 + (i // 2) % 599) for i in range(1800)]),
+                       ("config_3_1024", chains.offsets_for_config("c3")),
+                       ("one_sided_1024", list(range(1, 1025))),
+                       ("paired_900", [o for o in range(-450, 451) if o != 0]),
                        ("one_sided_6000", [1 + (i % 599) for i in range(6000)])):
         bank = sb.ChannelBank(sb.translators_for(ch, offs), ch.stage_tuples())
         want[name] = int(bank.info().matrix_pipe)
         bank.close()
-    assert want == {"paired_2400": 1, "one_sided_2400": 0, "paired_1800": 0, "one_sided_6000": 0}
+    assert want == {"paired_2400": 1, "one_sided_2400": 0, "config_3_1024": 1, "one_sided_1024": 0, "paired_900": 0, "one_sided_6000": 0}
 
 
 @pytest.mark.parametrize("n_ch", [3584, 10000])

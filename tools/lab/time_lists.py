@@ -32,7 +32,14 @@ def run(offs, matrix):
     return ms, int(info.matrix_pipe)
 
 
-lists = {
+lists_small = {
+    "c3: -512..511": list(range(-512, 512)),
+    "-511..511 w/o 0": [o for o in range(-511, 512) if o != 0],
+    "cycled 1024": chains.offsets_cycled(1024, 1200),
+    "-600..599 (1200)": list(range(-600, 600)),
+    "-750..749 mod (1500)": [((i + 600) % 1200) - 600 for i in range(-750, 750)],
+}
+lists_big = {
     "one-sided 2400": [1 + (i % 599) for i in range(2400)],
     "one-sided 6000": [1 + (i % 599) for i in range(6000)],
     "one-sided 10000": [1 + (i % 599) for i in range(10000)],
@@ -41,6 +48,7 @@ lists = {
     "3/4 paired 10000": [(-1) ** i * (1 + (i // 2) % 599) for i in range(7500)] + [1 + (i % 599) for i in range(2500)],
     "paired 6000": [(-1) ** i * (1 + (i // 2) % 599) for i in range(6000)],
 }
+lists = lists_small if (len(sys.argv) > 1 and sys.argv[1] == "small") else lists_big
 for name, offs in lists.items():
     v, _ = run(offs, 1)
     m, _ = run(offs, 2)
