@@ -74,13 +74,16 @@ void k_stage123m(const float2 *__restrict__ x_in, const float2 *__restrict__ tab
         reinterpret_cast<v4f *>(lds_m + G::off_zero)[i] = v4f{0.f, 0.f, 0.f, 0.f};
 
     const int n_seg = (a.n_y1 + fx::LSEG - 1) / fx::LSEG;   // segments that hold data
-    const int n_items = a.n_cgx * a.n_wt;
+    // item -> (set, time-wave) as in k_stage12m: the launch's sets x time-waves units, set-major, in eight equal runs, one per XCD
+    const int n_work = (a.n_chgroups - a.cg0) * a.n_wt;
+    const int n_items = a.n_cgx * 8;                        // (a.n_cgx: units of the XCD that has most)
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int xcd = item & 7;
-    const int qq = item >> 3;
-    const int wtm = qq % a.n_wt;
-    const int cgm = a.cg0 + (qq / a.n_wt) * 8 + xcd;
-    if (cgm >= a.n_chgroups) continue;
+    const int w0 = (int)(((long long)xcd * n_work) >> 3), w1 = (int)(((long long)(xcd + 1) * n_work) >> 3);
+    const int w = w0 + (item >> 3);
+    if (w >= w1) continue;
+    const int wtm = w % a.n_wt;
+    const int cgm = a.cg0 + w / a.n_wt;
     const int g_first = wtm * GT;                           // first segment group of the workgroup
     if (g_first * SPW >= n_seg) continue;
 

@@ -1831,8 +1831,8 @@ static int launch_k123_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStr
     K123mLaunch M = job->M3;
     M.args.cg0 = g_lo;
     M.args.n_chgroups = g_hi;
-    M.args.n_cgx = (g_hi - g_lo + 7) / 8 * 8;
-    M.grid = M.args.n_cgx * M.args.n_wt;
+    M.grid = (int)(((long long)(g_hi - g_lo) * M.args.n_wt + 7) / 8 * 8);
+    M.args.n_cgx = M.grid / 8;                                  // (units per XCD, as for k_stage12m)
     M.pa.slots = whole ? b->d_slots_m : b->d_slots_mp;
     M.pa.group_conj = nullptr;
     M.pa.n_slots = whole ? b->n_slots_m : b->n_slots_mp;
