@@ -75,20 +75,28 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     const int sg = wave / GT, tg = wave - sg * GT;          // this wave's slot group / segment group inside the workgroup
 
     // A workgroup takes the items blockIdx.x, blockIdx.x + gridDim.x, ... (the host launches one workgroup per item; a smaller
-    // grid makes the workgroups persistent).  item -> (slot-group set, time-wave): the launch's n_work = sets x time-waves units,
-    // in set-major order, are cut into eight equal runs, one per XCD (item % 8 under the round-robin placement of blocks;
-    // gridDim.x is a multiple of 8): the time-waves of a set share an XCD's L2 (one or two XCDs where a run ends inside a set),
-    // and no XCD has more than one unit more than another -- with whole sets per XCD, 17 sets were 3 on one XCD and 2 on the
-    // others (a bank of 1 024 channels: + 25 % on the launch), 163 sets 21 against 20.
-    const int n_work = (a.n_chgroups - a.cg0) * a.n_wt;
-    const int n_items = a.n_cgx * 8;                        // (a.n_cgx here: units of the XCD that has most = ceil(n_work / 8))
+    // grid makes the workgroups persistent).  item -> (slot-group set, time-wave): item % 8 is the XCD (round-robin placement of
+    // blocks; gridDim.x is a multiple of 8).  The sets go to the XCDs eight at a time, a whole set to an XCD -- its time-waves share
+    // that XCD's L2, and all XCDs work their way up the bank together (the tail kernel starts with the rows written last: Infinity
+    // Cache) --, but the last n_sets % 8 sets are dealt out by units (time-waves), in eight equal runs: with whole sets to the end,
+    // 17 sets were 3 on one XCD and 2 on the others (a bank of 1 024 channels: + 25 % on the launch), 163 sets 21 against 20.
+    const int n_sets = a.n_chgroups - a.cg0;
+    const int n_full = (n_sets >> 3) * a.n_wt;              // units of an XCD from whole rounds of eight sets
+    const int n_rem = (n_sets & 7) * a.n_wt;                // units of the last, partial round
+    const int n_items = a.n_cgx * 8;                        // (a.n_cgx here: units of the XCD that has most = n_full + ceil(n_rem / 8))
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int xcd = item & 7;
-    const int w0 = (int)(((long long)xcd * n_work) >> 3), w1 = (int)(((long long)(xcd + 1) * n_work) >> 3);
-    const int w = w0 + (item >> 3);
-    if (w >= w1) continue;
-    const int wtm = w % a.n_wt;                             // a.n_wt here: time-waves of GT segment groups
-    const int cgm = a.cg0 + w / a.n_wt;                     // set of GS slot groups
+    const int k = item >> 3;
+    int wtm, cgm;
+    if (k < n_full) {
+        wtm = k % a.n_wt;                                   // a.n_wt here: time-waves of GT segment groups
+        cgm = a.cg0 + (k / a.n_wt) * 8 + xcd;               // set of GS slot groups
+    } else {
+        const int w = ((xcd * n_rem) >> 3) + (k - n_full);
+        if (w >= (((xcd + 1) * n_rem) >> 3)) continue;
+        wtm = w % a.n_wt;
+        cgm = a.cg0 + (n_sets & ~7) + w / a.n_wt;
+    }
     const int gq = wtm / a.P, p = wtm - gq * a.P;
     const int bps = a.nb * a.P;
     const int g_first = gq * GT;                            // first segment group of the workgroup

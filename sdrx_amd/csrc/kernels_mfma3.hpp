@@ -74,16 +74,23 @@ void k_stage123m(const float2 *__restrict__ x_in, const float2 *__restrict__ tab
         reinterpret_cast<v4f *>(lds_m + G::off_zero)[i] = v4f{0.f, 0.f, 0.f, 0.f};
 
     const int n_seg = (a.n_y1 + fx::LSEG - 1) / fx::LSEG;   // segments that hold data
-    // item -> (set, time-wave) as in k_stage12m: the launch's sets x time-waves units, set-major, in eight equal runs, one per XCD
-    const int n_work = (a.n_chgroups - a.cg0) * a.n_wt;
+    // item -> (set, time-wave) as in k_stage12m: whole sets to the XCDs eight at a time, the last n_sets % 8 sets by units
+    const int n_sets = a.n_chgroups - a.cg0;
+    const int n_full = (n_sets >> 3) * a.n_wt, n_rem = (n_sets & 7) * a.n_wt;
     const int n_items = a.n_cgx * 8;                        // (a.n_cgx: units of the XCD that has most)
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int xcd = item & 7;
-    const int w0 = (int)(((long long)xcd * n_work) >> 3), w1 = (int)(((long long)(xcd + 1) * n_work) >> 3);
-    const int w = w0 + (item >> 3);
-    if (w >= w1) continue;
-    const int wtm = w % a.n_wt;
-    const int cgm = a.cg0 + w / a.n_wt;
+    const int k = item >> 3;
+    int wtm, cgm;
+    if (k < n_full) {
+        wtm = k % a.n_wt;
+        cgm = a.cg0 + (k / a.n_wt) * 8 + xcd;
+    } else {
+        const int w = ((xcd * n_rem) >> 3) + (k - n_full);
+        if (w >= (((xcd + 1) * n_rem) >> 3)) continue;
+        wtm = w % a.n_wt;
+        cgm = a.cg0 + (n_sets & ~7) + w / a.n_wt;
+    }
     const int g_first = wtm * GT;                           // first segment group of the workgroup
     if (g_first * SPW >= n_seg) continue;
 

@@ -1746,9 +1746,9 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
         M.L.args.n_chgroups = g_hi;
         // (the kernel walks items blockIdx.x, + gridDim.x, ...: a grid capped at the workgroups the chip holds at once makes it
         // persistent -- measured 3 % slower than one workgroup per item, which lets the dispatcher even out the last round)
-        // items = 8 x the units of the XCD that has most (kernels_mfma.hpp: eight equal runs of the sets x time-waves units)
-        M.L.grid = (int)(((long long)(g_hi - g_lo) * M.L.args.n_wt + 7) / 8 * 8);
-        M.L.args.n_cgx = M.L.grid / 8;                          // (k_stage12m reads it as units per XCD)
+        // items = 8 x the units of the XCD that has most (kernels_mfma.hpp: whole sets eight at a time, the last (sets % 8) by units)
+        M.L.args.n_cgx = ((g_hi - g_lo) / 8) * M.L.args.n_wt + (((g_hi - g_lo) % 8) * M.L.args.n_wt + 7) / 8;   // (k_stage12m reads it as units per XCD)
+        M.L.grid = M.L.args.n_cgx * 8;
         M.pa.slots = whole ? b->d_slots_m : b->d_slots_mp;
         M.pa.group_conj = nullptr;
         M.pa.n_slots = whole ? b->n_slots_m : b->n_slots_mp;
@@ -1831,8 +1831,8 @@ static int launch_k123_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStr
     K123mLaunch M = job->M3;
     M.args.cg0 = g_lo;
     M.args.n_chgroups = g_hi;
-    M.grid = (int)(((long long)(g_hi - g_lo) * M.args.n_wt + 7) / 8 * 8);
-    M.args.n_cgx = M.grid / 8;                                  // (units per XCD, as for k_stage12m)
+    M.args.n_cgx = ((g_hi - g_lo) / 8) * M.args.n_wt + (((g_hi - g_lo) % 8) * M.args.n_wt + 7) / 8;    // (units per XCD, as for k_stage12m)
+    M.grid = M.args.n_cgx * 8;
     M.pa.slots = whole ? b->d_slots_m : b->d_slots_mp;
     M.pa.group_conj = nullptr;
     M.pa.n_slots = whole ? b->n_slots_m : b->n_slots_mp;
