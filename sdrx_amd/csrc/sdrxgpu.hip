@@ -920,8 +920,8 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
         if (tune0.matrix_pipe == 0) {
             const long long max_chunk = cfg->max_in_len ? cfg->max_in_len : 512LL * b->m_total;
             const long long U = (max_chunk / b->MM + 1 + k12->Y2B - 1) / k12->Y2B;
-            const long long places = 2LL * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
-            auto launch_cost = [&](long long wgs_whole_segments) {            // min over lane lengths of rounds x (warm-up + bodies)
+            const long long n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            auto launch_cost = [&](long long wgs_whole_segments, long long places) {   // min over lane lengths of rounds x (warm-up + bodies)
                 double best = -1.0;
                 for (int nb = b->bps; nb >= 1; nb--) {
                     if (b->bps % nb) continue;
@@ -934,9 +934,11 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 return best;
             };
             const long long g16 = (U + 16LL * b->bps - 1) / (16LL * b->bps);                        // segment groups of 16
-            const double cost_m = launch_cost((long long)(m_slots_all.size() / m_set) * ((g16 + b->mGT - 1) / b->mGT));
-            const double cost_v = launch_cost(((long long)b->n_ch + 2 * kPairSlots - 1) / (2 * kPairSlots) * g16);
-            if (15.0 * cost_m >= 0.97 * 5.6 * cost_v) {
+            const long long places_m = n_cu_ * std::max<long long>(1, (long long)(160 * 1024 / k12m_lds_bytes(b->mGS, b->mGT)));
+            const double cost_m = launch_cost((long long)(m_slots_all.size() / m_set) * ((g16 + b->mGT - 1) / b->mGT), places_m);
+            const double cost_v = launch_cost(((long long)b->n_ch + 2 * kPairSlots - 1) / (2 * kPairSlots) * g16, 2 * n_cu_);
+            // (15.0 us: the 2 x 2 workgroup's body; other shapes -- a test knob -- in proportion to their waves)
+            if (15.0 * (b->mGS * b->mGT / 4.0) * cost_m >= 0.97 * 5.6 * cost_v) {
                 b->mfma = b->mfma3 = false;
                 b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
                 m_slots_all.clear();
