@@ -564,11 +564,22 @@ void k_stage12(const float2 *__restrict__ x_in, const float2 *__restrict__ table
     // blockIdx -> (channel group, time-wave).  Blocks are dealt round-robin over the 8 XCDs
     // (b % 8 labels the XCD group), so the time-waves of one channel group -- which read the same
     // translator tables -- are given the same b % 8 and consecutive b / 8: they meet in one XCD's L2.
+    // Whole channel groups go to the XCDs eight at a time; the last (groups % 8) of them are dealt out by units (time-waves), in
+    // eight equal runs -- a bank of fewer than eight groups reaches every XCD all the same (as k_stage12m, kernels_mfma.hpp).
     const int xcd = blockIdx.x & 7;
-    const int qq = blockIdx.x >> 3;
-    const int wt = qq % a.n_wt;
-    const int cg = a.cg0 + (qq / a.n_wt) * 8 + xcd;
-    if (cg >= a.n_chgroups) return;
+    const int kq = blockIdx.x >> 3;
+    const int n_groups = a.n_chgroups - a.cg0;
+    const int n_full = (n_groups >> 3) * a.n_wt, n_rem = (n_groups & 7) * a.n_wt;
+    int wt, cg;
+    if (kq < n_full) {
+        wt = kq % a.n_wt;
+        cg = a.cg0 + (kq / a.n_wt) * 8 + xcd;
+    } else {
+        const int w = ((xcd * n_rem) >> 3) + (kq - n_full);
+        if (w >= (((xcd + 1) * n_rem) >> 3)) return;
+        wt = w % a.n_wt;
+        cg = a.cg0 + (n_groups & ~7) + w / a.n_wt;
+    }
     const int g = wt / a.P;
     const int p = wt - g * a.P;
     const int bps = a.nb * a.P;                            // bodies per segment = spacing / SB
@@ -1033,11 +1044,21 @@ void k_stage12p(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
                 const Stage12Taps<T1, T2, TA> taps)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_p[];
+    // (whole slot groups to the XCDs eight at a time, the last (groups % 8) by units: as k_stage12)
     const int xcd = blockIdx.x & 7;
-    const int qq = blockIdx.x >> 3;
-    const int wt = qq % a.n_wt;
-    const int cg = a.cg0 + (qq / a.n_wt) * 8 + xcd;        // slot group
-    if (cg >= a.n_chgroups) return;
+    const int kq = blockIdx.x >> 3;
+    const int n_groups = a.n_chgroups - a.cg0;
+    const int n_full = (n_groups >> 3) * a.n_wt, n_rem = (n_groups & 7) * a.n_wt;
+    int wt, cg;                                            // time-wave, slot group
+    if (kq < n_full) {
+        wt = kq % a.n_wt;
+        cg = a.cg0 + (kq / a.n_wt) * 8 + xcd;
+    } else {
+        const int w = ((xcd * n_rem) >> 3) + (kq - n_full);
+        if (w >= (((xcd + 1) * n_rem) >> 3)) return;
+        wt = w % a.n_wt;
+        cg = a.cg0 + (n_groups & ~7) + w / a.n_wt;
+    }
     if (pa.group_conj[cg])
         stage12p_body<T1, T2, Y2B, W, CPW, true, MA, TA>(x_in, tables, y2_out, y3_out, seam_out, a, pa, taps, lds_p, cg, wt);
     else

@@ -1002,7 +1002,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     // the busiest CU gets m = ceil(workgroups / CUs) of them, runs them kmax at a time (LDS, registers), and a body
     // takes body_time(CPW, k) while k workgroups share the CU's SIMDs (fitted, in units of one 4-channel wave alone on
     // its SIMD); cost = (WU + nb) x that sum.  The kernel keeps a channel group's workgroups on one XCD (blockIdx % 8):
-    // fewer than 8 groups reach only that many XCDs.
+    // the last (groups % 8) groups go out by units, so every XCD is reached whatever the group count.
     {
         const long long U = ((long long)max_y2 + k12->Y2B - 1) / k12->Y2B;      // body slots per channel per call
         double best_cost = -1.0;
@@ -1028,7 +1028,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 const long long G = (U + (long long)SPW * b->bps - 1) / ((long long)SPW * b->bps);
                 const long long cgs = ((long long)b->n_ch + W * CPW - 1) / (W * CPW);
                 const long long wgs = cgs * G * P;
-                const long long cus = std::max<long long>(1, (long long)n_cu * std::min<long long>(8, cgs) / 8);
+                const long long cus = n_cu;      // (every XCD is reached whatever the group count: the last groups % 8 go out by units)
                 const long long m = (wgs + cus - 1) / cus;
                 const double cost = (double)(b->WU + nb) * ((double)(m / kmax) * body_time(CPW, kmax) + body_time(CPW, (int)(m % kmax)));
                 if (best_cost < 0 || cost < best_cost * 0.9999) {
@@ -1772,7 +1772,7 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
     P.L.args.cg0 = g_lo;
     P.L.args.n_chgroups = g_hi;
     P.L.args.n_cgx = (g_hi - g_lo + 7) / 8 * 8;
-    P.L.grid = P.L.args.n_cgx * P.L.args.n_wt;
+    P.L.grid = 8 * (((g_hi - g_lo) / 8) * P.L.args.n_wt + (((g_hi - g_lo) % 8) * P.L.args.n_wt + 7) / 8);   // (as launch_k12_range)
     P.pa.slots = b->d_slots;
     P.pa.group_conj = b->d_group_conj;
     P.pa.n_slots = b->n_slots;
@@ -1790,7 +1790,8 @@ static int launch_k12_range(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
     L.args.cg0 = cg_lo;
     L.args.n_chgroups = cg_hi;
     L.args.n_cgx = (cg_hi - cg_lo + 7) / 8 * 8;
-    L.grid = L.args.n_cgx * L.args.n_wt;
+    // (k_stage12: whole groups eight at a time, the last (groups % 8) by units: 8 x the units of the XCD that has most)
+    L.grid = 8 * (((cg_hi - cg_lo) / 8) * L.args.n_wt + (((cg_hi - cg_lo) % 8) * L.args.n_wt + 7) / 8);
     ProfScope ps(b, SDRXGPU_K_STAGE12, st);
     HIPCHK((b->fused ? b->k12->fn_fused : b->k12->fn)(L, st));
     return SDRXGPU_OK;
