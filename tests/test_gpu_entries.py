@@ -40,15 +40,16 @@ def _device_run(bank, blocks, n_ch, in_place):
     return outs
 
 
-@pytest.mark.parametrize("n_ch,fused", [(2304, sb.FUSED_AUTO), (4100, sb.FUSED_OFF), (4100, sb.FUSED_REQUIRE)])
-def test_host_entry_in_two_halves_equals_device_entry(n_ch, fused):
+@pytest.mark.parametrize("n_ch,fused,matrix", [(2304, sb.FUSED_AUTO, 2), (2304, sb.FUSED_OFF, 1), (4100, sb.FUSED_OFF, 2), (4100, sb.FUSED_REQUIRE, 0)])
+def test_host_entry_in_two_halves_equals_device_entry(n_ch, fused, matrix):
     ch = chains.chain("10")
     offs = chains.offsets_cycled(n_ch, ch.N)
     tabs = sb.translators_for(ch, offs)
     blocks = _blocks(ch, 3, car=[tabs[7]])
     # (matrix_pipe 2: k_stage12m + k_tail_s where a bank of this size takes the matrix pipe -- this test ends with a bit-for-bit
     # comparison of two cuts of the stream, which the default of such a bank, k_stage123m, does not promise: tests/test_gpu_fused3.py)
-    kw = dict(block_hint=0xFFFFFFFF, tuning={"fused_tail": fused, "matrix_pipe": 0 if fused == sb.FUSED_REQUIRE else 2})
+    # matrix: 2 = k_stage12m + k_tail_s, 1 = the vector kernels with the separate tail, 0 with fused_tail required = k_stage12p + k_tail4
+    kw = dict(block_hint=0xFFFFFFFF, tuning={"fused_tail": fused, "matrix_pipe": matrix})
     dev = sb.ChannelBank(tabs, ch.stage_tuples(), **kw)
     want = _device_run(dev, blocks, n_ch, in_place=True)
     dev.close()
