@@ -102,12 +102,17 @@ typedef struct {
  * (tests/test_gpu_parity.py); a choice whose tiles do not fit the CU's LDS, or that is not compiled for the chain,
  * makes sdrxgpu_bank_create fail. */
 typedef struct {
+    uint32_t struct_size;    /* = sizeof(sdrxgpu_tuning): checked by sdrxgpu_bank_create (fields have come and gone
+                                between versions of this header; a caller built against another layout is refused
+                                instead of having its values read as other fields)                            */
     uint32_t k12_waves;      /* waves per workgroup of the stage-1/2 kernel: 4, 8 or 16; 0 = auto            */
     uint32_t k12_cpw;        /* channels per wave of that kernel: 1, 2 or 4; 0 = auto                         */
     uint32_t tail_tile;      /* final outputs per workgroup of the separate tail kernel, 8..128; 0 = auto     */
     uint32_t tail_generic;   /* 1 = run-time-tap tail kernel even where a compile-time one exists             */
-    uint32_t fused_tail;     /* 0 = auto (from 6 000 channels, where it is the faster path); 1 = never run stage 3
-                                inside the stage-1/2 kernel; 2 = require it                                      */
+    uint32_t fused_tail;     /* stage 3 inside the VECTOR stage-1/2 kernel (k_stage12 / k_stage12p + k_tail4): 0 = auto
+                                (banks of 6 000 channels and more that stay on the vector kernels -- e.g. a channel list
+                                without conjugate partners; a bank that takes the matrix pipe runs k_stage12m + k_tail_s
+                                whatever its size), 1 = never, 2 = require it (and with it the vector kernels)        */
     uint32_t host_parts;     /* channel parts of sdrxgpu_bank_process (D2H of one beside the kernels of the next):
                                 0 = auto, 1..8                                                                */
     uint32_t pair_lanes;     /* two channels per lane of the stage-1/2 kernel (conjugate partners share the mixer):
@@ -278,6 +283,62 @@ int sdrxgpu_host_unregister(void *ptr);
 
 int sdrxgpu_bank_synchronize(sdrxgpu_bank *bank);
 int sdrxgpu_bank_get_info(sdrxgpu_bank *bank, sdrxgpu_bank_info *info);
+
+/* ---- one channel list over several GPUs of one node, in ONE process --------------------------------------------
+ * sdrx is one process with one device thread calling data_cb (src/sdrx.cpp:306-364); its only parallelism is one
+ * independent worker per channel (DS, src/ds.hpp:43-77).  A sdrxgpu_multibank keeps that shape across GPUs: the
+ * channel list is cut into contiguous ranges, one per device (sdrxgpu_shard_range's rule), every range is an
+ * sdrxgpu_bank of its own on its device with its own state, and ONE call processes one block on all of them:
+ *   - the block goes to every device by a host-to-device copy of its own from the caller's buffer (2.56 MB per
+ *     32 ms block of 10 MS/s; page-lock the buffer with sdrxgpu_host_register and it is one DMA per device) --
+ *     no collective, no traffic between GPUs, no RCCL;
+ *   - every device's output rows are copied straight into its slice of the caller's [n_channels][out_stride]
+ *     arrays (the chunk data_cb fills, iq_buf_ptr += CH_IQ_BUF_SIZE, sdrx.cpp:338/344);
+ *   - one worker thread per device drives its bank (DS's thread-per-worker model with devices as the workers), so
+ *     the devices run side by side; the call returns when all are done.
+ * Which stage-1/2 kernel family runs (tuning.matrix_pipe: the one choice whose outputs differ by rounding) is
+ * decided ONCE, for the whole channel list, and pinned in every shard: a channel's bits do not depend on how many
+ * devices the list is cut over, nor on which shard it lands in (tests/test_gpu_multibank.py).
+ * Not available through a multibank: the stereo mix-down (pan_pos: a sum over all channels), a caller's stream
+ * (cfg.stream belongs to one device), SDRXGPU_FLAG_PIPELINED.  cfg.device is ignored. */
+typedef struct sdrxgpu_multibank sdrxgpu_multibank;
+
+typedef struct {
+    uint32_t n_shards;         /* devices that hold a (non-empty) channel range */
+    uint32_t n_channels;
+    uint32_t m_total;
+    uint32_t matrix_pipe;      /* stage-1/2 kernel family of EVERY shard, as sdrxgpu_bank_info.matrix_pipe */
+    uint64_t samples_in, samples_out;
+    uint64_t device_bytes;     /* HBM held, all devices */
+} sdrxgpu_multibank_info;
+
+/* Contiguous [*lo, *hi) of shard `index` of `n_shards` over `n_items` items: the first n_items % n_shards shards take
+ * one item more.  Pure arithmetic (no device). */
+int sdrxgpu_shard_range(uint32_t n_items, uint32_t index, uint32_t n_shards, uint32_t *lo, uint32_t *hi);
+
+/* devices: HIP device ordinals, one shard each, in channel order; the same ordinal may appear more than once (two
+ * shards on one GPU: how the tests rehearse the path on a one-GPU box).  n_devices == 0 (devices may be NULL): every
+ * visible device.  With more devices than channels the last devices stay unused. */
+int sdrxgpu_multibank_create(const sdrxgpu_bank_cfg *cfg, const int32_t *devices, uint32_t n_devices, sdrxgpu_multibank **out);
+int sdrxgpu_multibank_destroy(sdrxgpu_multibank *mb);
+int sdrxgpu_multibank_reset(sdrxgpu_multibank *mb);
+
+/* sdrxgpu_bank_process over all devices: HOST pointers, outputs complete in caller memory on return.  A refused call
+ * (out_stride too small, ...) is refused before any device has been touched. */
+int sdrxgpu_multibank_process(sdrxgpu_multibank *mb, const sdrxgpu_iq *iq_in, size_t in_len, sdrxgpu_iq *iq_out,
+                              float *audio_out, size_t out_stride, size_t *out_len);
+/* sdrxgpu_bank_process_pinned over all devices: page-locked host block in, per-shard DEVICE output pointers
+ * (d_iq_out[s] / d_audio_out[s]: [channels of shard s][out_stride], on shard s's device; either array may be NULL),
+ * asynchronous on every shard's stream -- sdrxgpu_multibank_synchronize waits for all of them. */
+int sdrxgpu_multibank_process_pinned(sdrxgpu_multibank *mb, const sdrxgpu_iq *iq_in, size_t in_len, void *const *d_iq_out,
+                                     void *const *d_audio_out, size_t out_stride, size_t *out_len);
+int sdrxgpu_multibank_synchronize(sdrxgpu_multibank *mb);
+int sdrxgpu_multibank_get_info(sdrxgpu_multibank *mb, sdrxgpu_multibank_info *info);
+/* Shard `index` (0 .. n_shards-1): its bank (owned by the multibank; for the getters -- info, gains, squelch, profile --
+ * not for process calls), its device and its channel range.  Any pointer may be NULL. */
+int sdrxgpu_multibank_shard(sdrxgpu_multibank *mb, uint32_t index, sdrxgpu_bank **bank, int32_t *device, uint32_t *ch_lo, uint32_t *ch_hi);
+/* sdrxgpu_bank_get_agc_state over all shards, in channel order. */
+int sdrxgpu_multibank_get_agc_state(sdrxgpu_multibank *mb, float *agc_gain, float *agc_power, float *lf_gain, float *lf_power);
 
 /* Squelch SNR (dB) and state (0 closed / 1 open) per channel after the last chunk (what sdrx prints,
  * sdrx.cpp:593-634); either may be NULL. */

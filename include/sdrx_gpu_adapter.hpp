@@ -24,6 +24,10 @@
 //   * a copy of an MSD (Channel assignment, DS's internal copy) is the SAME channel, not a second
 //     delay line;
 //   * use_ftfir (EXPERIMENTAL in the reference, sdrx.cpp:1199) maps to SDRXGPU_FLAG_FTFIR.
+// Optional (one line in main): sdrxgpu::devices() = {0, 1, ..., 7} (or sdrxgpu::use_all_devices()) BEFORE the first block: the
+// channel list of every bank is then cut into contiguous ranges over these GPUs (sdrxgpu_multibank_*: per-device state, the block
+// H2D-copied to every device from `in`, every device's rows D2H-copied straight into its slice of the chunk, one worker thread
+// per device as DS has one per channel, ds.hpp:43-77).  Same calls, same bits as on one GPU; no RCCL, no second process.
 // Optional (one line in main): sdrxgpu::chunk_stride() = CH_IQ_BUF_SIZE promises that the output pointers of one
 // block are base + channel_index * stride -- what data_cb does with a ring chunk (iq_buf_ptr += CH_IQ_BUF_SIZE,
 // sdrx.cpp:338/344).  The GPU pass then lands directly in the chunk (CRB memory, crb.hpp:110) and the per-channel
@@ -59,6 +63,22 @@ inline size_t &chunk_stride()
     return v;
 }
 
+// Empty (default): one bank on the current HIP device.  Otherwise the HIP device ordinals the banks created afterwards are cut
+// over, in channel order (sdrxgpu_multibank_create); an ordinal may repeat.
+inline std::vector<int32_t> &devices()
+{
+    static std::vector<int32_t> v;
+    return v;
+}
+
+// every visible GPU (an 8-GPU node: devices() = {0, ..., 7}); for n < 0 nothing changes.  Needs no HIP header here: the count
+// comes from the library's own refusal of the first ordinal that does not exist.
+inline void use_devices(int n)
+{
+    devices().clear();
+    for (int d = 0; d < n; d++) devices().push_back(d);
+}
+
 namespace detail {
 
 struct StageCfg {
@@ -74,6 +94,7 @@ struct Group {
     bool lf_agc = false;
     std::vector<std::vector<iqsample_t>> translators;   // per channel, empty = no mixing
     sdrxgpu_bank *bank = nullptr;
+    sdrxgpu_multibank *multi = nullptr;  // instead of `bank` when sdrxgpu::devices() was set at the first block
     bool sealed = false;
     bool failed = false;
     size_t m_total = 1;
@@ -89,6 +110,7 @@ struct Group {
     ~Group()
     {
         if (bank) sdrxgpu_bank_destroy(bank);
+        if (multi) sdrxgpu_multibank_destroy(multi);
     }
 
     void fail(const std::string &what)
@@ -123,6 +145,11 @@ struct Group {
         cfg.channels = ch.data();
         sdrxgpu_agc_params_sdrx(&cfg.agc, &cfg.lf_agc);
         cfg.device = -1;
+        if (!devices().empty()) {
+            int rc = sdrxgpu_multibank_create(&cfg, devices().data(), (uint32_t)devices().size(), &multi);
+            if (rc != SDRXGPU_OK) fail(std::string("sdrxgpu_multibank_create: ") + sdrxgpu_strerror(rc));
+            return;
+        }
         int rc = sdrxgpu_bank_create(&cfg, &bank);
         if (rc != SDRXGPU_OK) fail(std::string("sdrxgpu_bank_create: ") + sdrxgpu_strerror(rc));
     }
@@ -148,9 +175,11 @@ struct Group {
             iqsample_t *dst = direct ? direct_base : iq.data();
             out_len = 0;
             if (!failed) {
-                int rc = sdrxgpu_bank_process(bank, reinterpret_cast<const sdrxgpu_iq *>(in), in_len,
-                                              reinterpret_cast<sdrxgpu_iq *>(dst), audio.data(), stride, &out_len);
-                if (rc != SDRXGPU_OK) fail(std::string("sdrxgpu_bank_process: ") + sdrxgpu_strerror(rc));
+                int rc = multi ? sdrxgpu_multibank_process(multi, reinterpret_cast<const sdrxgpu_iq *>(in), in_len,
+                                                           reinterpret_cast<sdrxgpu_iq *>(dst), audio.data(), stride, &out_len)
+                               : sdrxgpu_bank_process(bank, reinterpret_cast<const sdrxgpu_iq *>(in), in_len,
+                                                      reinterpret_cast<sdrxgpu_iq *>(dst), audio.data(), stride, &out_len);
+                if (rc != SDRXGPU_OK) fail(std::string(multi ? "sdrxgpu_multibank_process: " : "sdrxgpu_bank_process: ") + sdrxgpu_strerror(rc));
             }
             if (failed) {
                 out_len = in_len / m_total;

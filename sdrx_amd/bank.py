@@ -46,8 +46,12 @@ class AgcParams(C.Structure):
 
 class Tuning(C.Structure):
     """sdrxgpu_tuning: geometry / kernel-path overrides for tests and tuning runs (0 = automatic)."""
-    _fields_ = [(k, C.c_uint32) for k in ("k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail", "host_parts", "pair_lanes",
-                                            "matrix_pipe", "m_slot_groups", "m_seg_groups")]
+    _fields_ = [(k, C.c_uint32) for k in ("struct_size", "k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail", "host_parts",
+                                            "pair_lanes", "matrix_pipe", "m_slot_groups", "m_seg_groups")]
+
+    def __init__(self, **kw):
+        kw.setdefault("struct_size", C.sizeof(Tuning))
+        super().__init__(**kw)
 
 
 FUSED_AUTO, FUSED_OFF, FUSED_REQUIRE = 0, 1, 2
@@ -74,6 +78,11 @@ class BankInfo(C.Structure):
                 ("device_bytes", C.c_uint64), ("fused_tail", C.c_uint32), ("pair_lanes", C.c_uint32),
                 ("k12_waves", C.c_uint32), ("k12_cpw", C.c_uint32), ("k12_bodies", C.c_uint32),
                 ("matrix_pipe", C.c_uint32), ("m_slots", C.c_uint32)]
+
+
+class MultiBankInfo(C.Structure):
+    _fields_ = [("n_shards", C.c_uint32), ("n_channels", C.c_uint32), ("m_total", C.c_uint32), ("matrix_pipe", C.c_uint32),
+                ("samples_in", C.c_uint64), ("samples_out", C.c_uint64), ("device_bytes", C.c_uint64)]
 
 
 _lib = None
@@ -146,6 +155,17 @@ def load_library():
     L.sdrxgpu_bank_profile_enable.argtypes = [vp, C.c_int]
     L.sdrxgpu_bank_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sdrxgpu_bank_profile_reset.argtypes = [vp]
+    u32p = C.POINTER(C.c_uint32)
+    L.sdrxgpu_shard_range.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    L.sdrxgpu_multibank_create.argtypes = [C.POINTER(_Cfg), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(vp)]
+    L.sdrxgpu_multibank_destroy.argtypes = [vp]
+    L.sdrxgpu_multibank_reset.argtypes = [vp]
+    L.sdrxgpu_multibank_process.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(sz)]
+    L.sdrxgpu_multibank_process_pinned.argtypes = [vp, vp, sz, C.POINTER(vp), C.POINTER(vp), sz, C.POINTER(sz)]
+    L.sdrxgpu_multibank_synchronize.argtypes = [vp]
+    L.sdrxgpu_multibank_get_info.argtypes = [vp, C.POINTER(MultiBankInfo)]
+    L.sdrxgpu_multibank_shard.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_int32), u32p, u32p]
+    L.sdrxgpu_multibank_get_agc_state.argtypes = [vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -158,6 +178,9 @@ EXPORTED_SYMBOLS = [
     "sdrxgpu_audio_pos", "sdrxgpu_bank_get_mix", "sdrxgpu_bank_mix_buffers",
     "sdrxgpu_bank_profile_read", "sdrxgpu_bank_profile_reset", "sdrxgpu_strerror", "sdrxgpu_last_error",
     "sdrxgpu_version",
+    "sdrxgpu_shard_range", "sdrxgpu_multibank_create", "sdrxgpu_multibank_destroy", "sdrxgpu_multibank_reset", "sdrxgpu_multibank_process",
+    "sdrxgpu_multibank_process_pinned", "sdrxgpu_multibank_synchronize", "sdrxgpu_multibank_get_info", "sdrxgpu_multibank_shard",
+    "sdrxgpu_multibank_get_agc_state",
 ]
 
 
@@ -259,12 +282,19 @@ class ChannelBank:
     stages      : list of (m, float32 taps) -- the ``std::vector<MSD::Stage>`` of sdrx.cpp:1588-1672.
     """
 
-    def __init__(self, translators, stages, lf_agc=False, agc=None, agc_lf=None, device=-1, stream=None,
-                 max_in_len=0, block_hint=0, pipelined=False, ftfir=False, fused_stage3=False,
-                 audio_fir=None, audio_fir_gain_db=0.0, squelch=None, pan_pos=None, mix_fir=None, mix_fir_gain_db=0.0,
-                 modulation=None, tuning=None):
+    def __init__(self, translators, stages, **kw):
         L = load_library()
         self._L = L
+        cfg = self._make_cfg(translators, stages, **kw)
+        h = C.c_void_p()
+        _check(L.sdrxgpu_bank_create(C.byref(cfg), C.byref(h)), "sdrxgpu_bank_create")
+        self._h = h
+
+    def _make_cfg(self, translators, stages, lf_agc=False, agc=None, agc_lf=None, device=-1, stream=None,
+                  max_in_len=0, block_hint=0, pipelined=False, ftfir=False, fused_stage3=False,
+                  audio_fir=None, audio_fir_gain_db=0.0, squelch=None, pan_pos=None, mix_fir=None, mix_fir_gain_db=0.0,
+                  modulation=None, tuning=None):
+        """sdrxgpu_bank_cfg for these arguments; the arrays it points into stay alive as attributes of self."""
         n_ch = len(translators)
         self._taps = [np.ascontiguousarray(h, dtype=np.float32) for _, h in stages]
         st = (_Stage * len(stages))()
@@ -321,13 +351,12 @@ class ChannelBank:
             # dict of sdrxgpu_tuning fields, e.g. {"k12_waves": 8, "k12_cpw": 4} (tests / tuning runs only)
             self._tuning = Tuning(**tuning)
             cfg.tuning = C.pointer(self._tuning)
-        h = C.c_void_p()
-        _check(L.sdrxgpu_bank_create(C.byref(cfg), C.byref(h)), "sdrxgpu_bank_create")
-        self._h = h
         self.n_channels = n_ch
         self.m = 1
         for m, _ in stages:
             self.m *= int(m)
+        self._keep = (st, chs)
+        return cfg
 
     # ---- lifetime ----
     def close(self):
@@ -450,3 +479,92 @@ class ChannelBank:
         ms, n = C.c_double(), C.c_uint64()
         _check(self._L.sdrxgpu_bank_profile_read(self._h, kernel, C.byref(ms), C.byref(n)), "sdrxgpu_bank_profile_read")
         return ms.value, n.value
+
+
+def shard_range(n_items: int, index: int, n_shards: int):
+    """[lo, hi) of shard ``index``: sdrxgpu_shard_range, the rule a multibank cuts its channel list by (pure arithmetic, no GPU)."""
+    lo, hi = C.c_uint32(), C.c_uint32()
+    _check(load_library().sdrxgpu_shard_range(n_items, index, n_shards, C.byref(lo), C.byref(hi)), "sdrxgpu_shard_range")
+    return lo.value, hi.value
+
+
+class MultiChannelBank(ChannelBank):
+    """One channel list over several GPUs of one node in ONE process (``sdrxgpu_multibank``): contiguous channel ranges per
+    device, per-device state, one H2D copy of the block per device from the caller's buffer, outputs straight into each
+    device's slice of the caller's arrays; one call = all devices, complete on return.  Same constructor as
+    ``ChannelBank`` plus ``devices`` (HIP ordinals, one shard each; the same ordinal may repeat; empty = all visible)."""
+
+    def __init__(self, translators, stages, devices=(), **kw):
+        L = load_library()
+        self._L = L
+        cfg = self._make_cfg(translators, stages, **kw)
+        devs = (C.c_int32 * max(1, len(devices)))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        _check(L.sdrxgpu_multibank_create(C.byref(cfg), devs if len(devices) else None, len(devices), C.byref(h)), "sdrxgpu_multibank_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sdrxgpu_multibank_destroy(self._h)
+            self._h = None
+
+    def reset(self):
+        _check(self._L.sdrxgpu_multibank_reset(self._h), "sdrxgpu_multibank_reset")
+
+    def synchronize(self):
+        _check(self._L.sdrxgpu_multibank_synchronize(self._h), "sdrxgpu_multibank_synchronize")
+
+    def info(self) -> MultiBankInfo:
+        i = MultiBankInfo()
+        _check(self._L.sdrxgpu_multibank_get_info(self._h, C.byref(i)), "sdrxgpu_multibank_get_info")
+        return i
+
+    def shards(self):
+        """[(device, ch_lo, ch_hi, BankInfo)] per shard."""
+        out = []
+        for k in range(self.info().n_shards):
+            b, dev, lo, hi = C.c_void_p(), C.c_int32(), C.c_uint32(), C.c_uint32()
+            _check(self._L.sdrxgpu_multibank_shard(self._h, k, C.byref(b), C.byref(dev), C.byref(lo), C.byref(hi)), "sdrxgpu_multibank_shard")
+            bi = BankInfo()
+            _check(self._L.sdrxgpu_bank_get_info(b, C.byref(bi)), "sdrxgpu_bank_get_info")
+            out.append((dev.value, lo.value, hi.value, bi))
+        return out
+
+    def agc_state(self):
+        a = [np.empty(self.n_channels, dtype=np.float32) for _ in range(4)]
+        _check(self._L.sdrxgpu_multibank_get_agc_state(self._h, *[v.ctypes.data for v in a]), "sdrxgpu_multibank_get_agc_state")
+        return tuple(a)
+
+    def process(self, iq, out_stride=None, want_iq=True, want_audio=True, iq_out=None, audio_out=None):
+        """Host buffers in, host buffers out, all devices, complete on return (``sdrxgpu_multibank_process``)."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        stride = int(out_stride or (iq.shape[0] // self.m + 1))
+        if iq_out is not None or audio_out is not None:
+            stride = (iq_out if iq_out is not None else audio_out).shape[1]
+            want_iq, want_audio = iq_out is not None, audio_out is not None
+            audio = audio_out
+        else:
+            iq_out = np.zeros((self.n_channels, stride), dtype=np.complex64) if want_iq else None
+            audio = np.zeros((self.n_channels, stride), dtype=np.float32) if want_audio else None
+        n_out = C.c_size_t(0)
+        _check(self._L.sdrxgpu_multibank_process(self._h, iq.ctypes.data, iq.shape[0], iq_out.ctypes.data if want_iq else None,
+                                                 audio.ctypes.data if want_audio else None, stride, C.byref(n_out)),
+               "sdrxgpu_multibank_process")
+        k = n_out.value
+        return (iq_out[:, :k] if want_iq else None), (audio[:, :k] if want_audio else None)
+
+    def process_pinned(self, host_in_ptr, in_len, d_iq_out_ptrs, d_audio_out_ptrs, out_stride):
+        """Page-locked block in, one device pointer per shard out, asynchronous (``sdrxgpu_multibank_process_pinned``)."""
+        n = self.info().n_shards
+        mk = lambda ps: (C.c_void_p * n)(*ps) if ps is not None else None   # noqa: E731
+        n_out = C.c_size_t(0)
+        _check(self._L.sdrxgpu_multibank_process_pinned(self._h, host_in_ptr, in_len, mk(d_iq_out_ptrs), mk(d_audio_out_ptrs),
+                                                        out_stride, C.byref(n_out)), "sdrxgpu_multibank_process_pinned")
+        return n_out.value
+
+    # single-device entries that a multibank does not have
+    def _no(self, *a, **k):
+        raise SdrxGpuError(-5, "MultiChannelBank", "not available across devices (use the shards' banks)")
+
+    gains = squelch_state = mix = process_device = flush = ingest_buffer = ingest_buffer_after = _no
+    profile_enable = profile_reset = profile_read = _no

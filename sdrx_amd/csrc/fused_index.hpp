@@ -22,7 +22,7 @@
 // tests/test_fused_index.py holds this header to it.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SDRX_HD __host__ __device__ __forceinline__
 #else
 #define SDRX_HD inline

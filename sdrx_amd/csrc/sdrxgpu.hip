@@ -693,13 +693,13 @@ static int init_state(sdrxgpu_bank *b)
     return SDRXGPU_OK;
 }
 
-static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out);
+static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int *decide_only);
 
-extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
+// no C++ exception may cross the C ABI (host-side staging vectors of a very large bank can fail to allocate)
+static int bank_create_guarded(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int *decide_only)
 {
-    // no C++ exception may cross the C ABI (host-side staging vectors of a very large bank can fail to allocate)
     try {
-        const int rc = bank_create_impl(cfg, out);
+        const int rc = bank_create_impl(cfg, out, decide_only);
         g_creating = nullptr;
         return rc;
     } catch (const std::bad_alloc &) {
@@ -711,12 +711,24 @@ extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **o
     }
 }
 
-static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
+extern "C" int sdrxgpu_bank_create(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
 {
-    if (!cfg || !out) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: null argument");
-    *out = nullptr;
+    if (!out) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: null argument");
+    return bank_create_guarded(cfg, out, nullptr);
+}
+
+// decide_only != nullptr: run the validation and the choice of the stage-1/2 kernel family for this channel list (0 vector
+// kernels, 1 k_stage12m, 2 k_stage123m -- what bank_info.matrix_pipe would say), allocate nothing on the device, create no bank
+// (sdrxgpu_multibank_create: the choice is made ONCE for the whole list and pinned in every shard)
+static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int *decide_only)
+{
+    if (!cfg || (!out && !decide_only)) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: null argument");
+    if (out) *out = nullptr;
     if (cfg->struct_size != sizeof(sdrxgpu_bank_cfg))
         return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: struct_size %u != %zu", cfg->struct_size, sizeof(sdrxgpu_bank_cfg));
+    if (cfg->tuning && cfg->tuning->struct_size != sizeof(sdrxgpu_tuning))
+        return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.struct_size %u != %zu (built against another version of sdrx_gpu.h?)",
+                    cfg->tuning->struct_size, sizeof(sdrxgpu_tuning));
     if (cfg->n_channels == 0 || !cfg->channels) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: no channels");
     if (cfg->n_stages < 3 || cfg->n_stages > 4 || !cfg->stages)
         return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: %u stages (3 or 4 supported)", cfg->n_stages);
@@ -793,11 +805,11 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     const int halo = k12->M1 * (k12->T2 - k12->M2) + (k12->T1 - k12->M1);
     b->WU = (halo + b->SB - 1) / b->SB;
     b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
-    // Mixer + stage 1 on the f32 matrix pipe (k_stage12m): the 10 MS/s chain with translator tables, banks of
-    // 3 584 channels or more unless tuning says otherwise (measured against the vector kernels' automatic path, ms per block:
-    // 3 072 channels 0.408 / 0.359, 3 328: 0.417 / 0.374, 3 584: 0.380 / 0.397, 3 840: 0.389 / 0.416, 4 096: 0.427 / 0.464,
-    // 5 120: 0.548 / 0.571, 6 144: 0.594 / 0.648, 7 168: 0.691 / 0.727, 8 192: 0.725 / 0.831, 10 000: 0.863 / 0.990; up to
-    // 3 640 channels its workgroups all find a place at once).  Its input rows start T1 - M1 samples in front of a body.
+    // Mixer + stage 1 on the f32 matrix pipe (k_stage12m): the 10 MS/s chain with translator tables.  Automatic for
+    // banks of 1 024 channels or more whose launch, counted in rounds of workgroup places x bodies per lane for the bank's own
+    // channel list (how many channels found their conjugate partner decides the slot count), comes out under 0.97 of the pair
+    // kernel's -- decided further down, once the partners are known; tuning.matrix_pipe overrides.  Its input rows start
+    // T1 - M1 samples in front of a body.
     const sdrxgpu_tuning tune0 = cfg->tuning ? *cfg->tuning : sdrxgpu_tuning{};
     {
         const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && N > 0 && (N % 2) == 0;
@@ -850,10 +862,10 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
     b->tbl_stride = b->Neff + b->SB;
     // k_stage12m addresses translator rows by 32-bit byte offsets from the table base (LDS-DMA source = scalar base + lane offset)
     if (b->mfma && (uint64_t)b->n_ch * (uint64_t)b->tbl_stride * sizeof(float2) >= (1ull << 32)) {
-        if (tune0.matrix_pipe == 2) {
+        if (tune0.matrix_pipe >= 2) {
             free_bank(b);
-            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = 2, but %u tables of %d entries exceed k_stage12m's 32-bit row offsets",
-                        b->n_ch, b->tbl_stride);
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = %u, but %u tables of %d entries exceed the 32-bit row offsets of %s",
+                        tune0.matrix_pipe, b->n_ch, b->tbl_stride, tune0.matrix_pipe == 3 ? "k_stage123m" : "k_stage12m");
         }
         b->mfma = b->mfma3 = false;                             // automatic choice: the vector kernels
         b->HIST = ((b->WU * b->SB + b->MM + 7) / 8) * 8;
@@ -944,6 +956,12 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out)
                 m_slots_all.clear();
             }
         }
+    }
+
+    if (decide_only) {
+        *decide_only = b->mfma3 ? 2 : b->mfma ? 1 : 0;
+        free_bank(b);
+        return SDRXGPU_OK;
     }
 
     // tail-stage history: stage-2 outputs the remaining stages still need from earlier calls
@@ -2507,7 +2525,7 @@ extern "C" int sdrxgpu_bank_flush(sdrxgpu_bank *b, void *d_iq_out, void *d_audio
 extern "C" int sdrxgpu_host_register(void *ptr, size_t bytes)
 {
     if (!ptr || !bytes) return fail(SDRXGPU_ERR_INVALID_ARG, "host_register: null/empty range");
-    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterPortable));      // (portable: every device of a multibank copies from / to it)
     return SDRXGPU_OK;
 }
 
@@ -2566,3 +2584,5 @@ extern "C" int sdrxgpu_bank_get_squelch(sdrxgpu_bank *b, float *snr_db, unsigned
         for (uint32_t c = 0; c < b->n_ch; c++) state[c] = st[c].x;
     return SDRXGPU_OK;
 }
+
+#include "multibank.hpp"

@@ -117,6 +117,10 @@ int main(int argc, char **argv)
     const bool direct = mode.find("direct") != std::string::npos;
     const bool broken = mode == "broken_direct";      // promises a chunk layout, then hands out other pointers
     if (direct) sdrxgpu::chunk_stride() = CH_IQ_BUF_SIZE;
+    // optional: the bank cut over this many shards (all on device 0 -- the box has one GPU): sdrxgpu::devices(), the one line a
+    // multi-GPU sdrx adds to main()
+    const int n_shards = argc > 5 ? std::atoi(argv[5]) : 0;
+    if (n_shards > 0) sdrxgpu::devices() = std::vector<int32_t>((size_t)n_shards, 0);
     const size_t pitch = broken ? CH_IQ_BUF_SIZE + 8 : CH_IQ_BUF_SIZE;
 
     // stage list (what sdrx.cpp:1660-1668 builds for 10 MS/s), read from the file the test wrote
@@ -173,6 +177,8 @@ int main(int argc, char **argv)
     std::vector<Channel> serial_channels(use_pool ? n_ch : 0);
     if (use_pool)
         for (auto &ch : channels) ch.msd.decimate(nullptr, 0, nullptr);
+    // (... and that second bank on ONE device: pool_equals_serial is then also "cut over devices == not cut", bit for bit)
+    if (use_pool) sdrxgpu::devices().clear();
     for (int c = 0; c < (int)serial_channels.size(); c++) serial_channels[c].msd = sdrxgpu::MSD(tables[c], stages, false);
     std::vector<iqsample_t> serial_iq((size_t)serial_channels.size() * CH_IQ_BUF_SIZE);
     std::unique_ptr<WorkerPool> pool(use_pool ? new WorkerPool(4) : nullptr);
@@ -238,8 +244,8 @@ int main(int argc, char **argv)
     // a broken promise is reported (sticky error) and the rows still end up where the caller asked for them
     const bool err_ok = broken ? !sdrxgpu::last_error().empty() : sdrxgpu::last_error().empty();
     const bool ok = err_ok && worst_iq <= 1e-5 && worst_audio <= 1e-5 && pool_equals_serial;
-    std::printf("%s: mode=%s channels=%d blocks=%d rel_err iq=%.3e audio=%.3e %s\n", ok ? "PASS" : "FAIL", argv[4], n_ch, n_blocks,
-                worst_iq, worst_audio, sdrxgpu::last_error().c_str());
+    std::printf("%s: mode=%s channels=%d blocks=%d shards=%d rel_err iq=%.3e audio=%.3e %s\n", ok ? "PASS" : "FAIL", argv[4], n_ch, n_blocks,
+                n_shards, worst_iq, worst_audio, sdrxgpu::last_error().c_str());
     pool.reset();
     channels.clear();
     serial_channels.clear();

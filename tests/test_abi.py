@@ -83,3 +83,50 @@ def test_create_fails_loudly_without_gpu_or_with_bad_args(lib):
         with pytest.raises(sb.SdrxGpuError) as e:
             sb.ChannelBank([None], ch.stage_tuples())
         assert e.value.code == -2          # SDRXGPU_ERR_NO_DEVICE: no CPU fallback exists
+
+
+def test_shard_range_is_the_rule_the_ranks_use(lib):
+    """sdrxgpu_shard_range (how a multibank cuts its channel list over devices) == sdrx_amd.dist.shard_range (how bench.py's
+    ranks cut theirs): contiguous, complete, the first n % shards one longer.  Pure arithmetic, no GPU."""
+    from sdrx_amd import dist as sdist
+    for n in (0, 1, 5, 8, 9, 64, 1024, 8192, 10000):
+        for w in (1, 2, 3, 7, 8):
+            rs = [sb.shard_range(n, i, w) for i in range(w)]
+            assert rs == [sdist.shard_range(n, i, w) for i in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            sizes = [hi - lo for lo, hi in rs]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert sb.shard_range(10000, 3, 8) == (3750, 5000)
+    with pytest.raises(sb.SdrxGpuError):
+        sb.shard_range(10, 8, 8)
+    with pytest.raises(sb.SdrxGpuError):
+        sb.shard_range(10, 0, 0)
+
+
+def test_multibank_create_refuses_before_any_device_and_fails_loudly_without_one(lib):
+    ch = chains.chain("10")
+    tabs = sb.translators_for(ch, [1, -1, 2])
+    with pytest.raises(sb.SdrxGpuError) as e:       # a sum over all channels does not shard
+        sb.MultiChannelBank(tabs, ch.stage_tuples(), devices=(0, 0), pan_pos=[0, 1, -1])
+    assert e.value.code == -5
+    with pytest.raises(sb.SdrxGpuError) as e:
+        sb.MultiChannelBank(tabs, ch.stage_tuples(), devices=(0, 0), pipelined=True)
+    assert e.value.code == -5
+    with pytest.raises(sb.SdrxGpuError) as e:
+        sb.MultiChannelBank(tabs, ch.stage_tuples(), devices=(0, 0), stream=0x1000)
+    assert e.value.code == -1
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(sb.SdrxGpuError) as e:
+            sb.MultiChannelBank(tabs, ch.stage_tuples(), devices=(0, 0))
+        assert e.value.code == -2
+
+
+def test_tuning_struct_of_another_layout_is_refused(lib):
+    """sdrxgpu_tuning carries its size: a caller built against a header with other fields is told so instead of having its
+    values read as other fields."""
+    ch = chains.chain("10")
+    tabs = sb.translators_for(ch, [1])
+    with pytest.raises(sb.SdrxGpuError) as e:
+        sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"struct_size": 40, "matrix_pipe": 1})
+    assert e.value.code == -1 and "struct_size" in str(e.value)

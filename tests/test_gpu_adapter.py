@@ -48,6 +48,18 @@ def test_data_cb_loop_through_adapter(adapter_bin, mode):
     assert r.stdout.startswith("PASS")
 
 
+@pytest.mark.parametrize("mode,shards", [("serial", 2), ("ds_direct", 2), ("pool", 3), ("pool_direct", 2)])
+def test_data_cb_loop_through_adapter_cut_over_devices(adapter_bin, mode, shards):
+    """The same loop with sdrxgpu::devices() = {0, 0[, 0]}: the bank is a sdrxgpu_multibank (contiguous channel ranges, one
+    worker thread and one H2D / D2H per device).  Against the oracle in every mode; the pool modes also compare the cut bank
+    with an uncut one bit for bit."""
+    exe, taps, _ = adapter_bin
+    r = subprocess.run([exe, taps, "33", "3", mode, str(shards)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("PASS") and f"shards={shards}" in r.stdout
+
+
 def test_zero_copy_into_a_page_locked_chunk_ring(adapter_bin):
     """tests/cpp/adapter_ring.cpp: an 8-chunk ring with the reference CRB's semantics (src/crb.hpp:64-189), chunks page-locked,
     acquire -> data_cb loop through the adapter in chunk_stride() mode -> commit for 24 blocks, a consumer thread one chunk
