@@ -56,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--mgs", type=int, default=0, help="tuning.m_slot_groups (k_stage12m workgroup shape), 0 auto")
     ap.add_argument("--mgt", type=int, default=0, help="tuning.m_seg_groups, 0 auto")
     ap.add_argument("--tail-tile", type=int, default=0, help="tuning.tail_tile (final outputs per workgroup of the separate tail kernel), 0 auto")
+    ap.add_argument("--tail-agc", type=int, default=0, help="tuning.tail_agc: 0 auto, 1 k_tail_s + k_agc, 2 require k_tail_agc (tail stages + AGC in one kernel)")
+    ap.add_argument("--tail-agc-cpg", type=int, default=0, help="tuning.tail_agc_cpg (channels per workgroup of k_tail_agc), 0 auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--pipelined", action="store_true",
@@ -258,7 +260,8 @@ def selftest_launch(args):
 # ------------------------------------------------------------------------------------------------
 # rank mode
 # ------------------------------------------------------------------------------------------------
-def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch, events=True, expect=None, check=None):
+def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch, events=True, expect=None, check=None,
+              pipelined=False):
     """An input-check pass (expect: the generator's checksum of every ring block, known to every rank; check: dict that
     takes the counts), SETTLE + W untimed steps, then exactly `steps` timed steps bracketed by synchronize + barrier.
     events: HIP events around the dominant kernel inside the timed region (the headline configuration: roofline.achieved
@@ -286,9 +289,17 @@ def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring,
     def step():
         k = state["k"]
         cur = fan.get(k)                      # N > 1: the compute stream waits for block k's broadcast (issued a step ago)
-        fan.post(k + 1, block_for(k + 1))     # block k+1 starts moving into the bank's other input ring
+        if not pipelined:
+            fan.post(k + 1, block_for(k + 1))     # block k+1 starts moving into the bank's other input ring
         n = bank.process_device(cur.data_ptr(), L, d_iq.data_ptr(), d_au.data_ptr(), 512)
-        fan.done(k)
+        if pipelined:
+            # a pipelined bank reads the input of call k-1 until call k has been enqueued (include/sdrx_gpu.h): only now is
+            # ring (k-1) % 2 free for block k+1
+            if k > 0:
+                fan.done(k - 1)
+            fan.post(k + 1, block_for(k + 1))
+        else:
+            fan.done(k)
         assert n == 512 or (state["calls"] == 0 and n == 0)      # a pipelined bank returns block k-1 at call k
         state["k"] = k + 1
         state["calls"] += 1
@@ -491,9 +502,9 @@ def main():
         ring = torch.from_numpy(host).cuda()
 
     tuning = None
-    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile:
+    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile or args.tail_agc or args.tail_agc_cpg:
         tuning = {"fused_tail": args.fused, "pair_lanes": args.pair, "matrix_pipe": args.matrix, "m_slot_groups": args.mgs, "m_seg_groups": args.mgt,
-                  "tail_tile": args.tail_tile}
+                  "tail_tile": args.tail_tile, "tail_agc": args.tail_agc, "tail_agc_cpg": args.tail_agc_cpg}
     fused_seen = {}
     pair_seen = {}
     matrix_seen = {}
@@ -515,7 +526,7 @@ def main():
         d_au = torch.empty(len(offsets), 512, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
         dt, k = time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch, events=events,
-                          expect=expect if checked else None, check=check)
+                          expect=expect if checked else None, check=check, pipelined=args.pipelined)
         if args.pipelined:
             assert bank.flush(d_iq.data_ptr(), d_au.data_ptr(), 512) == 512
             torch.cuda.synchronize()

@@ -57,7 +57,12 @@ extern "C" {
                                             the AGC/demod of block k-1, and returns the outputs of block k-1 (one block
                                             = 32 ms of latency, like one more chunk in sdrx's ring of 8, sdrx.cpp:1742);
                                             sdrxgpu_bank_flush returns the last block.  Same outputs, bit for bit.
-                                            Measured: no faster than the default serial order. */
+                                            The two halves are two chains of work that do not wait for each other inside a
+                                            call, so the INPUT of call k (d_iq_in, or the ingest ring it was written to) is
+                                            read until call k+1 has been enqueued: in the bank's stream order a writer that
+                                            follows call k+1 (or sdrxgpu_bank_flush / _synchronize) is safe, one that follows
+                                            call k only is not -- the rule of sdrxgpu_bank_process_pinned.  Writing block k+1
+                                            into the bank's OTHER ring on the bank's stream right before call k+1 is fine.  */
 
 #define SDRXGPU_FLAG_FUSED_STAGE3   0x8u  /* large banks of the 10 MS/s chain (where the mixer + stage 1 run on the f32 matrix pipe): run
                                             decimator stages 2 and 3 in that kernel too, as one 119-tap filter, and keep no stage-2
@@ -129,6 +134,11 @@ typedef struct {
                                 this field where bit-identical results across layouts matter                     */
     uint32_t m_slot_groups;  /* k_stage12m workgroup = m_slot_groups x m_seg_groups tiles (waves) of 16 channel    */
     uint32_t m_seg_groups;   /*   pairs x 16 time segments: (2,2), (4,2) or (2,4); 0 = auto                        */
+    uint32_t tail_agc;       /* the remaining decimator stage(s) and the AGC / demodulator as ONE kernel (k_tail_agc: tiles of 32
+                                outputs handed from producer waves to the AGC waves through LDS; same bits as k_tail_s + k_agc):
+                                0 = auto = 1 = never (measured slower than the two kernels at every bank size),
+                                2 = require                                                                            */
+    uint32_t tail_agc_cpg;   /*   channels per workgroup of that kernel, 1..16; 0 = auto                               */
 } sdrxgpu_tuning;
 
 typedef struct {
@@ -198,6 +208,7 @@ typedef struct {
     uint32_t k12_bodies;       /*   bodies per lane */
     uint32_t matrix_pipe;      /* 1: mixer + stage 1 run on the f32 matrix pipe (k_stage12m); 2: and stages 2-3 in the same kernel (k_stage123m) */
     uint32_t m_slots;          /*   its channel-pair slots (pairs + channels without partner + padding) */
+    uint32_t tail_agc;         /* > 0: tail stages + AGC/demod run as one kernel (k_tail_agc); the channels per workgroup */
 } sdrxgpu_bank_info;
 
 /* Fill the AGC / LfAGC parameter blocks as sdrx configures them per channel

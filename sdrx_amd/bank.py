@@ -47,7 +47,7 @@ class AgcParams(C.Structure):
 class Tuning(C.Structure):
     """sdrxgpu_tuning: geometry / kernel-path overrides for tests and tuning runs (0 = automatic)."""
     _fields_ = [(k, C.c_uint32) for k in ("struct_size", "k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail", "host_parts",
-                                            "pair_lanes", "matrix_pipe", "m_slot_groups", "m_seg_groups")]
+                                            "pair_lanes", "matrix_pipe", "m_slot_groups", "m_seg_groups", "tail_agc", "tail_agc_cpg")]
 
     def __init__(self, **kw):
         kw.setdefault("struct_size", C.sizeof(Tuning))
@@ -77,7 +77,7 @@ class BankInfo(C.Structure):
                 ("history_len", C.c_uint32), ("samples_in", C.c_uint64), ("samples_out", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("fused_tail", C.c_uint32), ("pair_lanes", C.c_uint32),
                 ("k12_waves", C.c_uint32), ("k12_cpw", C.c_uint32), ("k12_bodies", C.c_uint32),
-                ("matrix_pipe", C.c_uint32), ("m_slots", C.c_uint32)]
+                ("matrix_pipe", C.c_uint32), ("m_slots", C.c_uint32), ("tail_agc", C.c_uint32)]
 
 
 class MultiBankInfo(C.Structure):

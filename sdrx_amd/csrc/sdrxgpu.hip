@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 #include "kernels_mfma.hpp"
 #include "kernels_mfma3.hpp"
+#include "kernels_tailagc.hpp"
 
 #include <algorithm>
 #include <complex>
@@ -408,7 +409,34 @@ static const K12Entry *find_k12(int M1, int T1, int M2, int T2)
     return nullptr;
 }
 
+// k_tail_agc (kernels_tailagc.hpp) for the tail of a chain: the kernel and the LDS of its fixed part (the index table comes on top)
+typedef void (*TailAgcKernel)(const TailAgcArgs);
+constexpr int kTaNT = 2;                                   // producer waves per workgroup
+static bool find_tail_agc(int mA, int tA, int mB, int tB, bool sq, bool fm, TailAgcKernel *k, size_t *lds)
+{
+#define SDRX_TA_PICK(MA_, TA_, MB_, TB_)                                                                                  \
+    if (mA == MA_ && tA == TA_ && mB == MB_ && tB == TB_) {                                                               \
+        *k = sq ? (fm ? &k_tail_agc<MA_, TA_, MB_, TB_, true, true, kTaNT> : &k_tail_agc<MA_, TA_, MB_, TB_, true, false, kTaNT>) \
+                : (fm ? &k_tail_agc<MA_, TA_, MB_, TB_, false, true, kTaNT> : &k_tail_agc<MA_, TA_, MB_, TB_, false, false, kTaNT>); \
+        *lds = fm ? tail_agc_lds_bytes<MA_, TA_, MB_, TB_, true, kTaNT>() : tail_agc_lds_bytes<MA_, TA_, MB_, TB_, false, kTaNT>(); \
+        return true;                                                                                                      \
+    }
+    SDRX_TA_PICK(5, 21, 5, 67)     // 10 MS/s
+    SDRX_TA_PICK(5, 19, 5, 45)     // 2.4 MS/s
+    SDRX_TA_PICK(0, 0, 5, 45)      // 0.96 / 1.2 / 1.44 / 1.6 / 1.92 MS/s
+    SDRX_TA_PICK(0, 0, 5, 67)      // 6 MS/s
+    SDRX_TA_PICK(0, 0, 2, 21)      // 2.56 MS/s
+#undef SDRX_TA_PICK
+    return false;
+}
+
 static long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) : a; }
+
+// largest bank (channels) that takes k_tail_agc automatically: none -- measured slower than k_tail_s + k_agc at every size
+// (64 channels 44 against 34 us, 1 024: 71 against 52), so it is a caller's choice (lab builds: -DSDRX_TAILAGC_AUTO_MAX=...)
+#ifndef SDRX_TAILAGC_AUTO_MAX
+#define SDRX_TAILAGC_AUTO_MAX 0
+#endif
 
 // ------------------------------------------------------------------------------------------
 // the bank
@@ -458,6 +486,11 @@ struct sdrxgpu_bank {
     size_t tail4_lds = 0;
     float2 *d_hist[2] = {nullptr, nullptr};   // stage-2 history, ping-pong between calls
     int hist_cur = 0;
+    // tail stages + AGC/demod as ONE kernel (k_tail_agc, kernels_tailagc.hpp): banks on the separate tail whose tail is a latency chain
+    bool tail_agc = false;
+    int ta_cpg = 4;                           //   channels per workgroup of that kernel
+    TailAgcKernel ta_kernel = nullptr;
+    size_t ta_lds = 0;                        //   LDS of its fixed part
     int tile_b = 64;                          // final outputs per k_tail workgroup (64: 8 workgroups per CU)
     bool tail_generic = false;                // tuning.tail_generic: run-time-tap k_tail even for the compiled-in chains
     size_t tail_lds = 0;
@@ -589,6 +622,9 @@ static int free_bank(sdrxgpu_bank *b)
         if (p && hipFree(p) != hipSuccess) n_bad++;
     };
     if (g_creating == b) g_creating = nullptr;
+    // every stream of the bank first (a pipelined bank's second chain is not ordered behind the bank's stream any more)
+    if (b->stream2) (void)hipStreamSynchronize(b->stream2);
+    if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (ProfSpan &s : b->prof_pending) {
         (void)hipEventDestroy(s.a);
@@ -1169,6 +1205,42 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         }
     }
 
+    // Tail stages + AGC/demod as ONE kernel (k_tail_agc, kernels_tailagc.hpp; bit-identical to k_tail_s + k_agc): for banks on the
+    // separate tail with one of the compiled-in tail chains.  A workgroup is `cpg` channels with two producer waves, so the
+    // launch has n_ch / cpg workgroups of four waves.  Never automatic: the producers do not keep up with the AGC chain they
+    // feed, the kernel is slower than the two it replaces; tuning.tail_agc = 2 asks for it.
+    {
+        const int mA = cfg->n_stages == 4 ? (int)b->m[2] : 0, tA = cfg->n_stages == 4 ? (int)b->ntaps[2] : 0;
+        const int mB = (int)b->m[cfg->n_stages - 1], tB = (int)b->ntaps[cfg->n_stages - 1];
+        bool any_fm_ = false;                      // (a bank of AM channels only keeps the AM-only kernel, as below for k_agc)
+        for (uint32_t c = 0; cfg->modulation && c < b->n_ch; c++) any_fm_ = any_fm_ || cfg->modulation[c] == SDRXGPU_MOD_FM;
+        const bool compiled = find_tail_agc(mA, tA, mB, tB, cfg->sql_level != nullptr, any_fm_, &b->ta_kernel, &b->ta_lds);
+        // (the index table: one entry per group of Y2B stage-2 outputs of the longest call)
+        const size_t lds_max = b->ta_lds + ((size_t)max_y2 / k12->Y2B + 2) * sizeof(uint32_t);
+        const bool can = compiled && !b->fused && !b->mfma3 && !b->tail_generic && lds_max <= 160 * 1024;
+        if (tune.tail_agc > 2 || tune.tail_agc_cpg > (uint32_t)kTaMaxCpg) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.tail_agc %u (0 = auto, 1 = never, 2 = require) / tail_agc_cpg %u (0 = auto, 1..%d)",
+                        tune.tail_agc, tune.tail_agc_cpg, kTaMaxCpg);
+        }
+        if (tune.tail_agc == 2 && !can) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.tail_agc = 2, but k_tail_agc is built for the separate tail of the reference's "
+                        "chains (not with stage 3 fused into the stage-1/2 kernel, not with tail_generic)");
+        }
+        const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        b->tail_agc = can && (tune.tail_agc == 2 || (tune.tail_agc == 0 && (int)b->n_ch <= SDRX_TAILAGC_AUTO_MAX));
+        // channels per workgroup: as few as still fill the chip once (2 workgroups per CU), at most 4 (two per producer wave)
+        b->ta_cpg = tune.tail_agc_cpg ? (int)tune.tail_agc_cpg : std::max(1, std::min(4, ((int)b->n_ch + 2 * n_cu - 1) / (2 * n_cu)));
+        if (b->tail_agc) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(b->ta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+            if (e != hipSuccess) {
+                free_bank(b);
+                return fail(SDRXGPU_ERR_HIP, "hipFuncSetAttribute(k_tail_agc, %zu B of LDS) failed: %s", lds_max, hipGetErrorString(e));
+            }
+        }
+    }
+
     // Host parts (sdrxgpu_bank_process copies the rows of part p out while the kernels of part p+1 run): fixed here
     // because the pairing below keeps partners inside one part.  Measured at 10 000 channels, page-locked buffers
     // (ms per block): 1 part 2.26, 2: 1.85, 3: 1.73, 4: 1.68, 5: 1.69, 8: 1.79 (smaller parts fill the chip less well);
@@ -1587,6 +1659,7 @@ extern "C" int sdrxgpu_bank_get_info(sdrxgpu_bank *b, sdrxgpu_bank_info *info)
     info->k12_bodies = (uint32_t)b->nb;
     info->matrix_pipe = b->mfma3 ? 2u : b->mfma ? 1u : 0u;
     info->m_slots = b->mfma ? (uint32_t)b->n_slots_m : 0u;
+    info->tail_agc = b->tail_agc ? (uint32_t)b->ta_cpg : 0u;
     return SDRXGPU_OK;
 }
 
@@ -2108,6 +2181,41 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
     t.iq_keep = iq_direct ? nullptr : b->d_keep;
     const float2 *iq_rows = iq_direct ? t.iq_out : b->d_keep;
     const int iq_rows_stride = iq_direct ? (int)out_stride : b->keep_stride;
+    // what the AGC / demodulator needs to know (k_agc, or the consumer waves of k_tail_agc)
+    bool agc_done = false;
+    auto make_agc_args = [&]() {
+        AgcArgs g;
+        g.iq = iq_rows;
+        g.iq_stride = iq_rows_stride;
+        g.audio = d_audio_out ? d_audio_out + out_off : b->d_audio_keep;
+        g.out_stride = d_audio_out ? (int)out_stride : b->keep_stride;
+        g.state = b->d_state;
+        g.n_ch = ch_hi;
+        g.ch_lo = ch_lo;
+        g.n_out = t.n_b;
+        g.lf_active = (b->flags & SDRXGPU_FLAG_LF_AGC_ACTIVE) ? 1 : 0;
+        g.audio_vec = (((uintptr_t)g.audio & 15) == 0 && (g.out_stride & 3) == 0) ? 1 : 0;
+        auto fill = [](AgcParams &p, const sdrxgpu_agc_params &s) {
+            p.attack = s.attack;
+            p.decay = s.decay;
+            p.reference = s.reference;
+            p.max_gain = s.max_gain;
+            p.min_gain = (s.max_gain > 0.0f) ? 1.0f / s.max_gain : 1.0f / 200.0f;   // agc.hpp:34, 42
+            p.alpha = s.alpha;
+        };
+        fill(g.agc, b->agc);
+        fill(g.lf, b->lf);
+        g.fm = b->d_fm;
+        g.fm_prev = b->d_fm_prev;
+        g.roll_from = job->roll_from;
+        g.roll_to = job->roll_to;
+        g.roll_cnt = last ? job->roll_cnt : 0;
+        if (last) job->roll_cnt = 0;
+        g.sql = b->squelch ? b->d_sql : nullptr;
+        g.ramp_up = b->squelch ? b->d_sq_tabs + 1024 : nullptr;      // 16-byte aligned (offsets are multiples of 512 floats)
+        g.ramp_down = b->squelch ? b->d_sq_tabs + 1536 : nullptr;
+        return g;
+    };
     if (b->mfma3) {
         // stage-3 outputs put together from k_stage123m's entries + last stage, one workgroup per channel (k_tail_c)
         TailCArgs f;
@@ -2157,6 +2265,21 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         else
             return fail(SDRXGPU_ERR_HIP, "internal: no k_tail4 for this chain");
         HIPCHK(hipGetLastError());
+    } else if (b->tail_agc && t.n_b > 0) {
+        // tail stages + AGC/demod in one kernel (k_tail_agc): the tile hand-over through LDS replaces the launch boundary
+        t.hist_in = b->d_hist[b->hist_cur];
+        t.hist_out = b->d_hist[b->hist_cur ^ 1];
+        TailAgcArgs f;
+        f.t = t;
+        f.g = make_agc_args();
+        f.cpg = b->ta_cpg;
+        f.n_groups = (t.n_y2_new + t.y2b - 1) >> t.y2b_shift;
+        const unsigned blocks = (n_part + (unsigned)f.cpg - 1) / (unsigned)f.cpg + (f.g.roll_cnt > 0 ? 1u : 0u);
+        ProfScope ps(b, SDRXGPU_K_TAIL);
+        hipLaunchKernelGGL(b->ta_kernel, dim3(blocks), dim3((kTaNT + 2) * kWave), b->ta_lds + (size_t)f.n_groups * sizeof(uint32_t), b->stream, f);
+        HIPCHK(hipGetLastError());
+        agc_done = true;
+        if (last) b->hist_cur ^= 1;
     } else {
         t.hist_in = b->d_hist[b->hist_cur];
         t.hist_out = b->d_hist[b->hist_cur ^ 1];
@@ -2181,48 +2304,26 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
 
     // ---- AGC -> |.| -> LF AGC ----
     if (t.n_b > 0) {
+        // (with k_tail_agc the recurrence has run already; what follows only needs to know where the audio rows are)
         AgcArgs g;
-        g.iq = iq_rows;
-        g.iq_stride = iq_rows_stride;
-        g.audio = d_audio_out ? d_audio_out + out_off : b->d_audio_keep;
-        g.out_stride = d_audio_out ? (int)out_stride : b->keep_stride;
-        g.state = b->d_state;
-        g.n_ch = ch_hi;
-        g.ch_lo = ch_lo;
-        g.n_out = t.n_b;
-        g.lf_active = (b->flags & SDRXGPU_FLAG_LF_AGC_ACTIVE) ? 1 : 0;
-        g.audio_vec = (((uintptr_t)g.audio & 15) == 0 && (g.out_stride & 3) == 0) ? 1 : 0;
-        auto fill = [](AgcParams &p, const sdrxgpu_agc_params &s) {
-            p.attack = s.attack;
-            p.decay = s.decay;
-            p.reference = s.reference;
-            p.max_gain = s.max_gain;
-            p.min_gain = (s.max_gain > 0.0f) ? 1.0f / s.max_gain : 1.0f / 200.0f;   // agc.hpp:34, 42
-            p.alpha = s.alpha;
-        };
-        fill(g.agc, b->agc);
-        fill(g.lf, b->lf);
-        g.fm = b->d_fm;
-        g.fm_prev = b->d_fm_prev;
-        g.roll_from = job->roll_from;
-        g.roll_to = job->roll_to;
-        g.roll_cnt = last ? job->roll_cnt : 0;
-        if (last) job->roll_cnt = 0;
-        const unsigned agc_blocks = (n_part + kWave - 1) / kWave + (g.roll_cnt > 0 ? 1u : 0u);
-        g.sql = b->squelch ? b->d_sql : nullptr;
-        g.ramp_up = b->squelch ? b->d_sq_tabs + 1024 : nullptr;      // 16-byte aligned (offsets are multiples of 512 floats)
-        g.ramp_down = b->squelch ? b->d_sq_tabs + 1536 : nullptr;
-        ProfScope ps(b, SDRXGPU_K_AGC);
-        if (b->squelch)
-            if (b->d_fm)
-                hipLaunchKernelGGL((k_agc<true, true>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<true>), b->stream, g);
+        if (agc_done) {
+            g.audio = d_audio_out ? d_audio_out + out_off : b->d_audio_keep;
+            g.out_stride = d_audio_out ? (int)out_stride : b->keep_stride;
+        } else {
+            g = make_agc_args();
+            const unsigned agc_blocks = (n_part + kWave - 1) / kWave + (g.roll_cnt > 0 ? 1u : 0u);
+            ProfScope ps(b, SDRXGPU_K_AGC);
+            if (b->squelch)
+                if (b->d_fm)
+                    hipLaunchKernelGGL((k_agc<true, true>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<true>), b->stream, g);
+                else
+                    hipLaunchKernelGGL((k_agc<true, false>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<false>), b->stream, g);
+            else if (b->d_fm)
+                hipLaunchKernelGGL((k_agc<false, true>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<true>), b->stream, g);
             else
-                hipLaunchKernelGGL((k_agc<true, false>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<false>), b->stream, g);
-        else if (b->d_fm)
-            hipLaunchKernelGGL((k_agc<false, true>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<true>), b->stream, g);
-        else
-            hipLaunchKernelGGL((k_agc<false, false>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<false>), b->stream, g);
-        HIPCHK(hipGetLastError());
+                hipLaunchKernelGGL((k_agc<false, false>), dim3(agc_blocks), dim3(4 * kWave), sizeof(AgcLds<false>), b->stream, g);
+            HIPCHK(hipGetLastError());
+        }
         // (banks with squelch, audio FIR or mix-down are never run in parts: these work on the whole bank)
         if (b->squelch) {
             SquelchArgs q;
@@ -2300,22 +2401,33 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
     return launch_tail(b, &job, d_iq_out, d_audio_out, out_stride, out_off, produced);
 }
 
-// Pipelined mode: stage-1/2 of THIS block on stream2, concurrently the tail + AGC of the PREVIOUS block on the
-// bank's stream (they bound on different resources: packed-fp32 issue vs. HBM); the two meet again before the
-// call's work on the bank's stream is complete.  Outputs (and *produced) are those of the previous block.
-static int run_chunk_pipelined(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_audio_out, size_t out_stride,
-                               size_t *produced)
+// Pipelined mode: two chains that never wait for each other inside a call.  Chain A (stream2): input copy, mixer + stages 1-2 and
+// the history roll of THIS block, one block after the other.  Chain B (the bank's stream): tail stages + AGC of the PREVIOUS
+// block, behind an event wait for that block's chain-A work.  Outputs (and *produced) are those of the previous block.
+//   * stream2 waits (ev_fork) for what the bank's stream holds when the call begins: the caller's producer of the input, and
+//     the tail of block k-2 -- the last reader of the stage-2 scratch block k is about to overwrite.  Both are long done when
+//     chain A gets there, so the wait costs nothing.
+//   * round 4 made the bank's stream wait for chain A again at the END of every call (so that "after the call, in stream
+//     order" covered the input): the trace (profiles/r05_trace_pipelined.txt) shows what that cost -- copy -> fork -> stage 1-2
+//     -> join -> next copy became ONE chain through two queues, 10 to 25 us per hand-over, and the mode gained nothing.  Now
+//     the join is taken at the start of the NEXT call, where the tail needs it anyway.  Contract (as for process_pinned): the
+//     input of call k is in use until call k+1 has been enqueued -- or sdrxgpu_bank_flush / _synchronize.
+static int run_chunk_pipelined(sdrxgpu_bank *b, const float2 *src, float2 *d_ingest, size_t in_len, float2 *d_iq_out, float *d_audio_out,
+                               size_t out_stride, size_t *produced)
 {
-    HIPCHK(hipEventRecord(b->ev_fork, b->stream));            // input copy (and everything before) done
+    HIPCHK(hipEventRecord(b->ev_fork, b->stream));
     HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+    // chain B first: the previous block's tail waits for the previous block's chain A (the record of ev_join made a call ago)
+    if (b->pending.valid) HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+    int rc = launch_tail(b, &b->pending, d_iq_out, d_audio_out, out_stride, 0, produced);
+    if (rc) return rc;
+    // chain A
+    if (src != d_ingest) HIPCHK(hipMemcpyAsync(d_ingest, src, in_len * sizeof(float2), hipMemcpyDeviceToDevice, b->stream2));
     sdrxgpu_bank::TailJob job;
     float2 *y2buf = b->y2_cur ? b->d_y2b : b->d_y2;
-    int rc = launch_stage12(b, in_len, b->stream2, y2buf, &job);
+    rc = launch_stage12(b, in_len, b->stream2, y2buf, &job);
     if (rc) return rc;
     HIPCHK(hipEventRecord(b->ev_join, b->stream2));
-    rc = launch_tail(b, &b->pending, d_iq_out, d_audio_out, out_stride, 0, produced);
-    if (rc) return rc;
-    HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join, 0));
     if (job.valid) {
         b->pending = job;
         b->y2_cur ^= 1;
@@ -2426,7 +2538,9 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
     while (done < in_len) {
         float2 *d_ingest = b->d_xr[b->xr] + ((long long)b->n_in - b->x_origin);
         const size_t n = std::min(in_len - done, (size_t)b->max_chunk);
-        if (in_is_host) {
+        if (b->pipelined) {
+            // (the copy belongs to chain A: run_chunk_pipelined)
+        } else if (in_is_host) {
             HIPCHK(hipMemcpyAsync(d_ingest, src + done, n * sizeof(float2), hipMemcpyHostToDevice, b->stream));
         } else if (src + done != d_ingest) {
             HIPCHK(hipMemcpyAsync(d_ingest, src + done, n * sizeof(float2), hipMemcpyDeviceToDevice, b->stream));
@@ -2437,7 +2551,7 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
             rc = run_chunk_host(b, n, iq_out, audio_out, out_stride, produced_total, &produced);
             if (rc) return rc;
         } else if (b->pipelined) {
-            rc = run_chunk_pipelined(b, n, (float2 *)iq_out, (float *)audio_out, out_stride, &produced);
+            rc = run_chunk_pipelined(b, src + done, d_ingest, n, (float2 *)iq_out, (float *)audio_out, out_stride, &produced);
             if (rc) return rc;
         } else {
             rc = run_chunk(b, n, (float2 *)iq_out, (float *)audio_out, out_stride, produced_total, &produced);
@@ -2517,6 +2631,7 @@ extern "C" int sdrxgpu_bank_flush(sdrxgpu_bank *b, void *d_iq_out, void *d_audio
         return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "flush: %d outputs per channel but out_stride is %zu", b->pending.t.n_b, out_stride);
     HIPCHK(hipSetDevice(b->device));
     size_t produced = 0;
+    if (b->pipelined && b->pending.valid) HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join, 0));   // the pending block's chain A
     int rc = launch_tail(b, &b->pending, (float2 *)d_iq_out, (float *)d_audio_out, out_stride, 0, &produced);
     if (out_len) *out_len = produced;
     return rc;

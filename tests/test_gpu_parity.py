@@ -362,6 +362,48 @@ def test_pipelined_mode_is_bit_identical_one_call_late():
     bank.close()
 
 
+@pytest.mark.parametrize("n_ch,zero_copy", [(1024, False), (1024, True), (40, True)])
+def test_pipelined_mode_back_to_back_without_waiting(n_ch, zero_copy):
+    """The two chains of a pipelined bank run free of each other (round 5): six blocks enqueued back to back, nothing waits
+    until the end.  The contract of the header -- the input of call k is in use until call k+1 has been enqueued -- is what the
+    loop below relies on: distinct input buffers, or (zero_copy) the bank's own two input rings written on the bank's stream
+    right before each call.  Same bits as the serial order."""
+    import torch
+    ch = chains.chain("10")
+    offs = chains.offsets_for_config("c3") if n_ch == 1024 else list(range(-20, 20))
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    blocks = [synth.synth_iq(23, b * L, L, 0.25, [tabs[3]], [0.3], ch.N, 10000) for b in range(6)]
+    serial = sb.ChannelBank(tabs, ch.stage_tuples())
+    want = [serial.process(x) for x in blocks]
+    fam = serial.info().matrix_pipe
+    serial.close()
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        bank = sb.ChannelBank(tabs, ch.stage_tuples(), pipelined=True, stream=ts.cuda_stream)
+        assert bank.info().matrix_pipe == fam
+        d_x = [torch.from_numpy(x.view(np.float32).reshape(L, 2).copy()).cuda() for x in blocks]
+        d_iq = [torch.zeros(n_ch, 512, 2, device="cuda") for _ in range(7)]
+        d_au = [torch.zeros(n_ch, 512, device="cuda") for _ in range(7)]
+        torch.cuda.synchronize()
+        for k in range(6):
+            src = d_x[k].data_ptr()
+            if zero_copy:
+                p, cap = bank.ingest_buffer()
+                torch.as_tensor(sb.DeviceView(p, (L, 2)), device="cuda").copy_(d_x[k], non_blocking=True)    # on the bank's stream
+                src = p
+            n = bank.process_device(src, L, d_iq[k].data_ptr(), d_au[k].data_ptr(), 512)
+            assert n == (0 if k == 0 else 512)
+        assert bank.flush(d_iq[6].data_ptr(), d_au[6].data_ptr(), 512) == 512
+        bank.synchronize()
+        torch.cuda.synchronize()
+    for k in range(6):
+        got_iq = d_iq[k + 1].cpu().numpy().view(np.complex64)[..., 0]
+        assert np.array_equal(got_iq.view(np.uint32), want[k][0].view(np.uint32)), k
+        assert np.array_equal(d_au[k + 1].cpu().numpy().view(np.uint32), want[k][1].view(np.uint32)), k
+    bank.close()
+
+
 def test_two_banks_two_threads_concurrently(oracle):
     """BASELINE config 5's per-GPU share: independent IQ streams = independent banks, each driven from its own
     host thread on its own HIP stream, at the same time; no state outside the banks."""
