@@ -65,8 +65,17 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL fan-out even with one rank (rehearsal of the N > 1 path on one GPU)")
-    ap.add_argument("--fanout", choices=("pipelined", "inline"), default="pipelined",
-                    help="A/B: broadcast of block k+1 beside the kernels of block k (default), or block k in line before its kernels")
+    ap.add_argument("--fanout", choices=("host", "rccl", "pipelined", "inline"), default="host",
+                    help="how the one IQ stream's block reaches every rank: host (default) = rank 0's blocks lie in a shared page-locked "
+                         "ring in host memory and every rank copies its own H2D on its bank's copy stream (sdrxgpu_bank_process_pinned; "
+                         "SURVEY 8e: 'simply 8 independent pinned-host H2D copies'; no RCCL communicator at all, gloo carries the "
+                         "barrier and the max-over-ranks); rccl (= pipelined) = RCCL broadcast of block k+1 over xGMI into the banks' "
+                         "other input ring beside the kernels of block k; inline = that broadcast in line before block k's kernels (A/B)")
+    ap.add_argument("--ranks-on-one-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses GPU 0 (host fan-out only: RCCL refuses two ranks on one device)")
+    ap.add_argument("--multibank", type=int, default=0,
+                    help="D > 0: ONE process, the channel list cut over D devices by sdrxgpu_multibank (--channels per device; devices "
+                         "0..D-1, or D shards on GPU 0 when the box has fewer): the in-process form of the multi-GPU path a drop-in sdrx uses")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU-only check of the launcher and the fan-out: gloo ranks, no GPU, no channelizer work")
     return ap.parse_args(argv)
@@ -102,6 +111,30 @@ def spawn_ranks(args):
     if line_json:
         print(line_json, flush=True)
     sys.exit(rc if rc else (0 if line_json else 1))
+
+
+# ------------------------------------------------------------------------------------------------
+# stdout carries ONE line
+# ------------------------------------------------------------------------------------------------
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Libraries print banners on stdout (RCCL's version block, gloo's "connected to N peer ranks"); the contract is one JSON
+    line there.  From here on file descriptor 1 goes where stderr goes; emit() writes to the real one."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line: str):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -216,7 +249,27 @@ def selftest_launch(args):
     bad = checked = 0
     dist.barrier()
     t0 = time.perf_counter()
-    if plan.broadcast:
+    if plan.broadcast and args.fanout == "host":
+        # host fan-out: rank 0 lays the stream's blocks into a ring in shared host memory, every rank maps it and reads its blocks
+        # there by itself (on a GPU: its own H2D copy); nothing else crosses ranks.  Only rank 0 generates; the others check what
+        # they READ against what the generator makes.
+        n_ring = 4
+        shm_path = "/dev/shm/sdrx_selftest_ring_%s" % os.environ.get("MASTER_PORT", "0")
+        if rank == 0:
+            mm = np.memmap(shm_path, dtype=np.float32, mode="w+", shape=(n_ring, L, 2))
+            for b in range(n_ring):
+                mm[b] = block(7, b).numpy()
+            mm.flush()
+        dist.barrier()
+        if rank != 0:
+            mm = np.memmap(shm_path, dtype=np.float32, mode="r+", shape=(n_ring, L, 2))
+        dist.barrier()
+        if rank == 0:
+            os.unlink(shm_path)
+        for k in range(steps):
+            bad += int(sdist.block_checksum(np.array(mm[k % n_ring])) != sdist.block_checksum(block(7, k % n_ring)))
+            checked += 1
+    elif plan.broadcast:
         bufs = [torch.empty(L, 2), torch.empty(L, 2)]
         fan = sdist.PipelinedFanout(dist, bufs, src=0)
         fan.post(0, block(7, 0) if rank == 0 else None)
@@ -250,7 +303,8 @@ def selftest_launch(args):
                           "unit": "Mch-samples/s", "n_gpus": world, "steps": steps, "warmup": 0, "ms_per_step": dt / steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "selftest (gloo, CPU; launcher, plan, block transport and input check only) of: " + plan.workload,
-                                     "name": plan.name, "channels_total": int(t[2].item()), "parallelism": plan.parallelism + f" ({world} gloo ranks)"},
+                                     "name": plan.name, "channels_total": int(t[2].item()), "parallelism": plan.parallelism + f" ({world} gloo ranks)",
+                                     "fanout": args.fanout if plan.broadcast else None},
                           "input_check": {"blocks_checked": int(t[1].item()), "blocks_wrong": int(t[0].item())},
                           "selftest": {"blocks_received_wrong": int(t[0].item())}}), flush=True)
     dist.destroy_process_group()
@@ -261,7 +315,7 @@ def selftest_launch(args):
 # rank mode
 # ------------------------------------------------------------------------------------------------
 def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch, events=True, expect=None, check=None,
-              pipelined=False):
+              pipelined=False, host_ring=None, red_dev="cuda"):
     """An input-check pass (expect: the generator's checksum of every ring block, known to every rank; check: dict that
     takes the counts), SETTLE + W untimed steps, then exactly `steps` timed steps bracketed by synchronize + barrier.
     events: HIP events around the dominant kernel inside the timed region (the headline configuration: roofline.achieved
@@ -271,11 +325,25 @@ def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring,
     def block_for(k):
         return ring[k % n_ring] if rank == 0 else None
 
-    fan.post(0, block_for(0))
+    if host_ring is None:
+        fan.post(0, block_for(0))
 
     # Input check, outside the timed region: every block of the ring travels the way the timed blocks do (rank 0's ring ->
     # fan-out -> this rank's bank input ring) and every rank compares the checksum of what ARRIVED with the generator's.
-    if expect is not None:
+    if expect is not None and host_ring is not None:
+        # host fan-out: the block is H2D-copied by this rank itself from the shared page-locked ring; what is checked is what
+        # arrived in the bank's input ring (where sdrxgpu_bank_ingest_buffer said the block would land)
+        for _ in range(n_ring):
+            k = state["k"]
+            where = bank.ingest_buffer()[0]
+            assert bank.process_pinned(host_ring[k % n_ring], L, d_iq.data_ptr(), d_au.data_ptr(), 512) == 512
+            bank.synchronize()
+            got = sdist.block_checksum(torch.as_tensor(sb.DeviceView(where, (L, 2)), device="cuda").cpu())
+            check["blocks_checked"] += 1
+            check["blocks_wrong"] += int(got != expect[k % n_ring])
+            state["k"] = k + 1
+            state["calls"] += 1
+    elif expect is not None:
         for _ in range(n_ring):
             k = state["k"]
             cur = fan.get(k)
@@ -286,7 +354,16 @@ def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring,
             fan.done(k)
             state["k"] = k + 1
 
-    def step():
+    def step_host():
+        # host fan-out: this rank's own H2D copy of block k from the shared page-locked ring, on the bank's copy stream into the
+        # input ring the previous block's kernels are not reading; nothing waits, nothing is exchanged between ranks
+        k = state["k"]
+        n = bank.process_pinned(host_ring[k % n_ring], L, d_iq.data_ptr(), d_au.data_ptr(), 512)
+        assert n == 512
+        state["k"] = k + 1
+        state["calls"] += 1
+
+    def step_fan():
         k = state["k"]
         cur = fan.get(k)                      # N > 1: the compute stream waits for block k's broadcast (issued a step ago)
         if not pipelined:
@@ -304,11 +381,14 @@ def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring,
         state["k"] = k + 1
         state["calls"] += 1
 
+    step = step_host if host_ring is not None else step_fan
+
     # Clock settling, untimed and in front of the W warm-up steps: from idle the chip needs ~50 ms of this load before
     # its clock is steady (measured per step: 1.24, 1.35, 1.61, 1.52, ... 1.22 at step 12, 1.15 from step ~40 on).
     # A fixed number of steps, the same on every rank (each step is a collective when N > 1).
     for _ in range(SETTLE_STEPS + warmup):
         step()
+    bank.synchronize()          # (the bank's own streams: copy stream and, pipelined, its second chain)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -319,11 +399,12 @@ def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring,
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    bank.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    dt = sdist.max_over_ranks(dist, dt, device="cuda")
+    dt = sdist.max_over_ranks(dist, dt, device=red_dev)
     k = {}
     if events:
         ms, n = bank.profile_read(sb.K_STAGE12)
@@ -342,7 +423,9 @@ def time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring,
         ms, n = bank.profile_read(kid)
         k[name] = (ms / max(n, 1), int(n))
     bank.profile_enable(0)
-    fan.get(state["k"])          # drain the broadcast that is still in flight
+    if host_ring is None:
+        fan.get(state["k"])      # drain the broadcast that is still in flight
+    bank.synchronize()
     torch.cuda.synchronize()
     return dt, k
 
@@ -398,7 +481,7 @@ def run_c5(args, plan, ch, rank, local_rank, world, dist, torch, np, sb, sdist, 
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    dt = sdist.max_over_ranks(dist, time.perf_counter() - t0, device="cuda")
+    dt = sdist.max_over_ranks(dist, time.perf_counter() - t0, device=args.red_dev)
     k12_ms, k12_n = banks[0].profile_read(sb.K_STAGE12)
     k12_ms /= max(k12_n, 1)
     banks[0].profile_enable(0)
@@ -408,7 +491,7 @@ def run_c5(args, plan, ch, rank, local_rank, world, dist, torch, np, sb, sdist, 
         bk.close()
     n_wrong = check["blocks_wrong"]
     if dist is not None:
-        tw = torch.tensor([check["blocks_checked"], check["blocks_wrong"]], dtype=torch.int64, device="cuda")
+        tw = torch.tensor([check["blocks_checked"], check["blocks_wrong"]], dtype=torch.int64, device=args.red_dev)
         dist.all_reduce(tw)
         check = {"blocks_checked": int(tw[0].item()), "blocks_wrong": int(tw[1].item())}
         n_wrong = check["blocks_wrong"]
@@ -438,10 +521,88 @@ def run_c5(args, plan, ch, rank, local_rank, world, dist, torch, np, sb, sdist, 
             "input_check": check,
             "cpu_baseline": cpu_baseline(ch, args.cpu_seconds) if (world == 1 and not args.no_cpu_baseline) else None,
         }
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
     sys.exit("input check failed: %d block(s) arrived different from what the generator made" % n_wrong if n_wrong else 0)
+
+
+def run_multibank(args, torch, np, sb, chains, synth, sdist):
+    """--multibank D: ONE process, one channel list of D x --channels instances cut over D devices by sdrxgpu_multibank
+    (include/sdrx_gpu.h): per-device state, one H2D copy of the block per device from the caller's page-locked buffer, one worker
+    thread per device -- the in-process form of the channel shard, what a drop-in sdrx (one process, one device thread calling
+    data_cb, reference src/sdrx.cpp:306-364; workers src/ds.hpp:43-77) gets through the adapter's sdrxgpu::devices().  Devices
+    0..D-1, or D shards on GPU 0 when the box has fewer (rehearsal: then n_gpus = 1 and the shards share the one card).
+    Two numbers: the throughput entry (page-locked block in, per-shard device rows out, asynchronous) as `value`, and the
+    drop-in entry (host pointers in and out, complete on return) under host_pointer_entry."""
+    D = args.multibank
+    n_dev = torch.cuda.device_count()
+    devices = list(range(D)) if D <= n_dev else [0] * D
+    ch = chains.chain(args.rate)
+    L = ch.block_len
+    n_ch = args.channels * D
+    offs = chains.offsets_cycled(n_ch, ch.N)
+    tabs = sb.translators_for(ch, offs)
+    tuning = {"matrix_pipe": args.matrix} if args.matrix else None
+    mb = sb.MultiChannelBank(tabs, ch.stage_tuples(), devices=devices, tuning=tuning)
+    shards = mb.shards()
+    outs = [(torch.empty(hi - lo, 512, 2, device=f"cuda:{dev}"), torch.empty(hi - lo, 512, device=f"cuda:{dev}")) for dev, lo, hi, _ in shards]
+    p_iq, p_au = [o[0].data_ptr() for o in outs], [o[1].data_ptr() for o in outs]
+    n_ring = 8
+    car = [sb.make_translator(ch.N, ch.z, o) for o in (5, -20)]
+    ring = np.stack([synth.synth_iq(1234, b * L, L, 0.25, car, [0.3, 0.1], ch.N, ch.fs // 1000).view(np.float32).reshape(L, 2) for b in range(n_ring)])
+    sb.host_register(ring)
+    ptrs = [ring[b].ctypes.data for b in range(n_ring)]
+    state = {"k": 0}
+
+    def step():
+        assert mb.process_pinned(ptrs[state["k"] % n_ring], L, p_iq, p_au, 512) == 512
+        state["k"] += 1
+
+    for _ in range(SETTLE_STEPS + args.warmup):
+        step()
+    mb.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    mb.synchronize()
+    dt = time.perf_counter() - t0
+    for o in outs:
+        assert bool(torch.isfinite(o[0]).all()) and bool(torch.isfinite(o[1]).all())
+    # the drop-in entry: host pointers in and out (the ring chunk page-locked), all devices, complete on return
+    chunk = np.zeros((n_ch, 512), np.complex64)
+    audio = np.zeros((n_ch, 512), np.float32)
+    x_host = np.ascontiguousarray(ring[0]).view(np.complex64).reshape(L)
+    for a_ in (chunk, audio):
+        sb.host_register(a_)
+    for _ in range(3):
+        mb.process(x_host, iq_out=chunk, audio_out=audio)
+    n_it = 10
+    t1 = time.perf_counter()
+    for _ in range(n_it):
+        mb.process(x_host, iq_out=chunk, audio_out=audio)
+    dth = (time.perf_counter() - t1) / n_it
+    info = mb.info()
+    fam = int(info.matrix_pipe)
+    mb.close()
+    value = float(n_ch) * L * args.steps / dt / 1e6
+    emit(json.dumps({
+        "metric": "IQ Msamples/s ingested x channels demodulated (channel-samples/s)", "value": value, "unit": "Mch-samples/s",
+        "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.channels} channel instances per shard x {D} shards = {n_ch} channels from one IQ stream, 8.33 kHz grid; "
+                               f"{args.rate} MS/s, 32 ms blocks of {L} complex<float>, mixer + 4-stage FIR decimation /{ch.m_total} + IF-AGC + AM envelope",
+                   "name": "multibank", "channels_total": n_ch, "shards": D, "devices": devices,
+                   "parallelism": f"ONE process: sdrxgpu_multibank, {D} shard(s) on device(s) {sorted(set(devices))}, one worker thread + one H2D "
+                                  "copy of the block per shard from the caller's page-locked buffer, no communicator",
+                   "kernel_family": ["vector kernels", "k_stage12m", "k_stage123m"][fam],
+                   "includes": "PCIe H2D of every block, once per shard (sdrxgpu_multibank_process_pinned)",
+                   "realtime_factor": value * 1e6 / (n_ch * ch.fs), "settle_steps": SETTLE_STEPS},
+        "host_pointer_entry": {"what": "sdrxgpu_multibank_process: host pointers in and out (page-locked chunk), every shard's rows D2H into its "
+                                       "slice of the chunk, complete on return", "ms_per_block": dth * 1e3, "value": n_ch * L / dth / 1e6,
+                               "unit": "Mch-samples/s"},
+        "roofline": None, "cpu_baseline": None}))
+    sys.exit(0)
 
 
 def main():
@@ -458,6 +619,7 @@ def main():
     # distinct queues, 0.33 when they collide; 8 queues: 0.26 either way).  Must be set before the HIP runtime starts.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+    quiet_stdout()
     import numpy as np
     import torch  # before libsdrxgpu: it then binds to the HIP runtime torch ships (one runtime per process)
     from sdrx_amd import bank as sb
@@ -467,7 +629,19 @@ def main():
     rank, local_rank, world = sdist.env_rank_world()
     if world > 1:
         args.gpus = world
+    if args.multibank:
+        run_multibank(args, torch, np, sb, chains, synth, sdist)                                 # does not return
+    if args.fanout == "pipelined":
+        args.fanout = "rccl"
+    if args.ranks_on_one_gpu:
+        if args.fanout != "host":
+            sys.exit("--ranks-on-one-gpu needs --fanout host (RCCL refuses two ranks on one device)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    # host fan-out: nothing of the data path goes through a communicator, so there is none: gloo (CPU) carries the barrier, the
+    # max-over-ranks and the input-check counts.  rccl / inline: backend nccl (= RCCL), the block travels by broadcast.
+    backend = "gloo" if args.fanout == "host" else "nccl"
+    args.red_dev = "cpu" if backend == "gloo" else "cuda"
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -476,7 +650,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ch = chains.chain(args.rate)
     plan = sdist.plan(args.config, rank, world, ch.N, args.channels)
@@ -498,7 +675,29 @@ def main():
                      for b in range(n_ring)])
     expect = [sdist.block_checksum(host[b]) for b in range(n_ring)]
     check = {"blocks_checked": 0, "blocks_wrong": 0}
-    if rank == 0:
+    host_ring = None
+    use_host = args.fanout == "host" and (world > 1 or args.force_dist)
+    if use_host:
+        # Host fan-out: rank 0 owns the stream and lays its blocks into a ring in SHARED host memory (what the device thread's
+        # double buffer is in sdrx, airspy_dev.cpp:410-414, made visible to the other ranks); every rank maps it, page-locks its
+        # mapping and copies block k H2D itself.  The other ranks never see `host`: they read what rank 0 wrote.
+        shm_path = "/dev/shm/sdrx_bench_ring_%s" % os.environ.get("MASTER_PORT", "0")
+        if rank == 0:
+            mm = np.memmap(shm_path, dtype=np.float32, mode="w+", shape=(n_ring, L, 2))
+            mm[:] = host
+            mm.flush()
+        if dist is not None:
+            dist.barrier()
+        if rank != 0:
+            mm = np.memmap(shm_path, dtype=np.float32, mode="r+", shape=(n_ring, L, 2))
+        shared = np.asarray(mm)
+        sb.host_register(shared)
+        host_ring = [shared[b].ctypes.data for b in range(n_ring)]
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            os.unlink(shm_path)              # (the mappings keep the memory; nothing is left behind if a rank dies)
+    elif rank == 0:
         ring = torch.from_numpy(host).cuda()
 
     tuning = None
@@ -521,12 +720,12 @@ def main():
         p0, cap = bank.ingest_buffer()
         p1 = bank.ingest_buffer_after(L)
         recv = [torch.as_tensor(sb.DeviceView(p, (L, 2)), device="cuda") for p in (p0, p1)]
-        fan = sdist.PipelinedFanout(dist, recv, src=0, force=args.force_dist, inline=args.fanout == "inline")
+        fan = sdist.PipelinedFanout(dist if not use_host else None, recv, src=0, force=args.force_dist, inline=args.fanout == "inline")
         d_iq = torch.empty(len(offsets), 512, 2, dtype=torch.float32, device="cuda")
         d_au = torch.empty(len(offsets), 512, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
         dt, k = time_bank(bank, fan, ring, rank, dist, L, d_iq, d_au, steps, warmup, n_ring, sb, sdist, torch, events=events,
-                          expect=expect if checked else None, check=check, pipelined=args.pipelined)
+                          expect=expect if checked else None, check=check, pipelined=args.pipelined, host_ring=host_ring, red_dev=args.red_dev)
         if args.pipelined:
             assert bank.flush(d_iq.data_ptr(), d_au.data_ptr(), 512) == 512
             torch.cuda.synchronize()
@@ -540,7 +739,7 @@ def main():
     dt, k = run(offs, args.steps, args.warmup, checked=True)
     n_wrong = check["blocks_wrong"]
     if dist is not None:
-        tw = torch.tensor([check["blocks_checked"], check["blocks_wrong"]], dtype=torch.int64, device="cuda")
+        tw = torch.tensor([check["blocks_checked"], check["blocks_wrong"]], dtype=torch.int64, device=args.red_dev)
         dist.all_reduce(tw)
         check = {"blocks_checked": int(tw[0].item()), "blocks_wrong": int(tw[1].item())}
         n_wrong = check["blocks_wrong"]
@@ -680,9 +879,13 @@ def main():
                 "name": plan.name,
                 "channels_per_gpu": n_ch, "channels_total": plan.channels_total, "sample_rate": ch.fs, "block_len": L,
                 "outputs_per_channel_per_block": 512,
-                "parallelism": plan.parallelism +
-                               (", block k+1 broadcast over xGMI into the banks' other input ring while block k is processed"
-                                if (world > 1 or args.force_dist) else ""),
+                "parallelism": (plan.parallelism.replace("RCCL rank", "rank") if use_host else plan.parallelism) +
+                               ((", every rank copies block k+1 H2D itself from rank 0's shared page-locked ring on its bank's copy stream "
+                                 "while block k is processed (no communicator, no traffic between GPUs; gloo for the barrier)") if use_host else
+                                (", block k+1 broadcast by RCCL over xGMI into the banks' other input ring while block k is processed"
+                                 if (world > 1 or args.force_dist) else "")),
+                "fanout": (args.fanout if (world > 1 or args.force_dist) else None),
+                "includes": ("PCIe H2D of every block (host fan-out: the block is in host memory when a step starts)" if use_host else None),
                 "kernel_path": ("mixer + stage 1 on the f32 matrix pipe, stages 2-3 in the same kernel, no stage-2 scratch (k_stage123m + k_tail_c + k_agc)" if fused3 else
                                 ("stage 3 fused behind stages 1-2 (k_stage12 + k_tail4 + k_agc)" if fused else
                                  "separate tail (k_stage12 + k_tail_s + k_agc)") +
@@ -734,7 +937,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ch, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
     if n_wrong:

@@ -169,6 +169,25 @@ def test_two_rank_gloo_independent_streams_equal_a_single_process(oracle, tmp_pa
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("fanout", ["host", "rccl"])
+def test_bench_fanouts_under_two_gloo_ranks(fanout):
+    """The two ways the one stream's block reaches every rank (bench.py --fanout): host = rank 0's blocks in a ring in shared host
+    memory that every rank maps and reads itself (default: no communicator in the data path, SURVEY 8e's "independent pinned-host
+    H2D copies"), rccl = double-buffered broadcast.  On CPU: the transport and the input check of every block on every rank."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch", "--steps", "9", "--config", "c4",
+                        "--fanout", fanout], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["fanout"] == fanout
+    assert d["input_check"]["blocks_wrong"] == 0 and d["input_check"]["blocks_checked"] == 18
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("sdrx_selftest_ring_")]      # nothing left behind
+
+
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("config", ["c4", "c5"])
 def test_bench_configs_run_under_two_gloo_ranks(config):
     """`python bench.py --gpus 2 --config c4|c5 --selftest-launch`: launcher, plan, block transport (broadcast resp. the ranks'
