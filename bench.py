@@ -510,11 +510,16 @@ def run_c5(args, plan, ch, rank, local_rank, world, dist, torch, np, sb, sdist, 
                                    f"decimation /{ch.m_total} + IF-AGC + AM envelope",
                        "name": plan.name, "channels_per_gpu": plan.channels_per_gpu, "channels_total": plan.channels_total,
                        "streams_per_gpu": len(plan.seeds), "sample_rate": ch.fs, "block_len": L, "parallelism": plan.parallelism,
+                       "kernel_path": ("mixer + stage 1 on the f32 matrix pipe (k_stage12m)" if infos[0].matrix_pipe else
+                                       "vector kernels" + (", two channels per lane" if infos[0].pair_lanes else "")) +
+                                      ("; stage 3 fused behind stages 1-2 (k_tail4)" if infos[0].fused_tail else "; separate tail (k_tail_s)"),
                        "includes": "PCIe H2D of every block (the configuration is about that overlap; inputs are NOT resident in HBM "
                                    "when a step starts -- unlike the headline line)",
                        "realtime_factor": value * 1e6 / (plan.channels_total * ch.fs),
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "settle_steps": SETTLE_STEPS},
-            "roofline": {"bound": "valu_fp32", "kernel": "k_stage12p (one bank's launch while the other bank's kernels share the chip)",
+            "roofline": {"bound": "mfma" if infos[0].matrix_pipe else "valu_fp32",
+                         "kernel": ("k_stage123m" if infos[0].matrix_pipe == 2 else "k_stage12m" if infos[0].matrix_pipe else
+                                    "k_stage12p" if infos[0].pair_lanes else "k_stage12") + " (one bank's launch while the other bank's kernels share the chip)",
                          "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TF if ach else None,
                          "flops_per_unit": f12, "traffic": None, "launches": int(k12_n),
                          "whole_step_tflops": flops_per_channel_sample(ch, len(ch.stages)) * units * len(plan.seeds) / (dt / args.steps) / 1e12},
@@ -761,11 +766,39 @@ def main():
     if world == 1 and not args.no_extra_configs and plan.name == "headline" and tuning is None and matrix_main == 1:
         # the same workload with SDRXGPU_FLAG_FUSED_STAGE3 (k_stage123m + k_tail_c: no stage-2 scratch; opt-in because of its rounding,
         # include/sdrx_gpu.h)
-        dtb, kb = run(offs, max(30, args.steps), args.warmup, tuning_override={"matrix_pipe": 3})
-        nb_steps = max(30, args.steps)
-        extra["the workload with SDRXGPU_FLAG_FUSED_STAGE3 (stages 2-3 in the stage-1 kernel, no stage-2 scratch; opt-in)"] = {
-            "value": n_ch * L * nb_steps / dtb / 1e6, "unit": "Mch-samples/s", "ms_per_step": dtb / nb_steps * 1e3,
-            "realtime_factor": L * nb_steps / dtb / ch.fs, "kernel_ms_avg": {n: v[0] for n, v in kb.items()}}
+        key3 = "the workload with SDRXGPU_FLAG_FUSED_STAGE3 (stages 2-3 in the stage-1 kernel, no stage-2 scratch; opt-in)"
+        try:
+            dtb, kb = run(offs, max(30, args.steps), args.warmup, tuning_override={"matrix_pipe": 3})
+            nb_steps = max(30, args.steps)
+            extra[key3] = {"value": n_ch * L * nb_steps / dtb / 1e6, "unit": "Mch-samples/s", "ms_per_step": dtb / nb_steps * 1e3,
+                           "realtime_factor": L * nb_steps / dtb / ch.fs, "kernel_ms_avg": {n: v[0] for n, v in kb.items()}}
+        except sb.SdrxGpuError as e:          # (e.g. --block-hint N: k_stage123m takes whole segments per lane only)
+            extra[key3] = {"refused": str(e)}
+
+    if world == 1 and not args.no_extra_configs and plan.name == "headline" and not use_host:
+        # BASELINE configs[3], one GPU's share (= --config c4 at N = 1): configs[2]'s 1 024 channels with every block arriving the
+        # way an N-GPU run's blocks do -- H2D by this rank from a page-locked ring (the host fan-out) -- and, for comparison, the
+        # same bank with SDRXGPU_FLAG_PIPELINED (call k returns block k-1; two free-running chains)
+        o = chains.offsets_for_config("c3")
+        hb_ring = np.ascontiguousarray(host)
+        sb.host_register(hb_ring)
+        n_it = max(100, args.steps)
+        saved, saved_p = host_ring, args.pipelined
+        try:
+            host_ring = [hb_ring[b_].ctypes.data for b_ in range(n_ring)]
+            dte, ke = run(o, n_it, args.warmup, events=False)
+            extra["1024 channels per GPU, every block H2D by the rank itself from a page-locked ring (configs[3] per GPU = --config c4 --fanout host at N = 1)"] = {
+                "value": len(o) * L * n_it / dte / 1e6, "unit": "Mch-samples/s", "ms_per_step": dte / n_it * 1e3,
+                "realtime_factor": L * n_it / dte / ch.fs, "kernel_ms_avg": {n: v[0] for n, v in ke.items()},
+                "includes": "PCIe H2D of every block (sdrxgpu_bank_process_pinned)"}
+            host_ring, args.pipelined = None, True
+            dte, ke = run(o, n_it, args.warmup, events=False)
+            extra["1024 channels (configs[2]) with SDRXGPU_FLAG_PIPELINED: call k returns block k-1"] = {
+                "value": len(o) * L * n_it / dte / 1e6, "unit": "Mch-samples/s", "ms_per_step": dte / n_it * 1e3,
+                "realtime_factor": L * n_it / dte / ch.fs, "call_semantics": "pipelined: call k returns block k-1 (bit-identical outputs, one block of latency)"}
+        finally:
+            host_ring, args.pipelined = saved, saved_p
+            sb.host_unregister(hb_ring)
 
     if world == 1 and not args.no_extra_configs and plan.name == "headline":
         # BASELINE configs[4], one GPU's share: 2 independent 10 MS/s streams x 1024 channels, each stream's block
@@ -861,6 +894,8 @@ def main():
             "k_tail": {"ms": k["k_tail"][0], "bound": "hbm", "algorithmic_bytes": tail_bytes,
                        "achieved_gbs": tail_bytes / (k["k_tail"][0] / 1e3) / 1e9 if k["k_tail"][1] else None,
                        "frac": tail_bytes / (k["k_tail"][0] / 1e3) / 1e9 / HBM_PEAK_GBS if k["k_tail"][1] else None,
+                       "frac_is": "the bytes the kernel must move (algorithmic_bytes: its inputs once + its outputs) over the 8 TB/s HBM spec peak; "
+                                  "measured traffic: roofline.traffic_step / the committed PMC profile",
                        "does": ("k_tail_c: stage-3 outputs put together from k_stage123m's entries + stage 4" if fused3 else
                                 "k_tail4: range-boundary stage-3 outputs + stage 4" if fused else "k_tail_s: stages 3-4 from the stage-2 scratch")},
             "k_agc": {"ms": k["k_agc"][0], "bound": "latency (512 dependent steps per channel)",

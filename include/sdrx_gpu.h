@@ -74,6 +74,18 @@ extern "C" {
                                             full scale over a floor of 0.25, beyond it under one of 0.6; profiles/r04_b_parity_pairs.jsonl),
                                             and a different cut of the stream into calls changes the last bits.  Off by default. */
 
+#define SDRXGPU_FLAG_REFERENCE_ORDER 0x10u /* only kernels that add every FIR in the reference's own order (msd.hpp:309-331: folded, outside
+                                            in, mixer product first) -- the vector kernels, which are bit-identical among themselves
+                                            whatever the bank's size, channel list or sharding.  Without it a bank of >= 1 024 channels
+                                            whose channels come in +k / -k pairs takes the f32 matrix pipe for the mixer + stage 1
+                                            (k_stage12m: 15 % less time per 10 000-channel block), whose P -+ Q formulation is 1.2 to
+                                            1.75 x the reference's own Release-vs-portable deviation away from the reference where the
+                                            vector kernels are 0.9 to 1.4 x: within 1e-5 wherever the reference's two builds agree to
+                                            0.5e-5, and up to 1.1e-5 in two of the 30 stress cases where the vector kernels hold
+                                            1e-5 (the weak partner of a carrier at 0.9 of full scale over a floor of 0.05: 1.06e-5
+                                            against 6.4e-6).  Same as tuning.matrix_pipe = 1, as a
+                                            flag an application sets. */
+
 typedef struct sdrxgpu_bank sdrxgpu_bank;
 
 /* std::complex<float> / iqsample_t */

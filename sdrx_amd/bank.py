@@ -24,6 +24,7 @@ FLAG_LF_AGC_ACTIVE = 0x1
 FLAG_PIPELINED = 0x2
 FLAG_FTFIR = 0x4
 FLAG_FUSED_STAGE3 = 0x8
+FLAG_REFERENCE_ORDER = 0x10
 
 
 class SdrxGpuError(RuntimeError):
@@ -291,7 +292,7 @@ class ChannelBank:
         self._h = h
 
     def _make_cfg(self, translators, stages, lf_agc=False, agc=None, agc_lf=None, device=-1, stream=None,
-                  max_in_len=0, block_hint=0, pipelined=False, ftfir=False, fused_stage3=False,
+                  max_in_len=0, block_hint=0, pipelined=False, ftfir=False, fused_stage3=False, reference_order=False,
                   audio_fir=None, audio_fir_gain_db=0.0, squelch=None, pan_pos=None, mix_fir=None, mix_fir_gain_db=0.0,
                   modulation=None, tuning=None):
         """sdrxgpu_bank_cfg for these arguments; the arrays it points into stay alive as attributes of self."""
@@ -310,7 +311,7 @@ class ChannelBank:
         d_agc, d_lf = sdrx_agc_params()
         cfg = _Cfg()
         cfg.struct_size = C.sizeof(_Cfg)
-        cfg.flags = (FLAG_LF_AGC_ACTIVE if lf_agc else 0) | (FLAG_PIPELINED if pipelined else 0) | (FLAG_FTFIR if ftfir else 0) | (FLAG_FUSED_STAGE3 if fused_stage3 else 0)
+        cfg.flags = (FLAG_LF_AGC_ACTIVE if lf_agc else 0) | (FLAG_PIPELINED if pipelined else 0) | (FLAG_FTFIR if ftfir else 0) | (FLAG_FUSED_STAGE3 if fused_stage3 else 0) | (FLAG_REFERENCE_ORDER if reference_order else 0)
         cfg.n_stages = len(stages)
         cfg.stages = st
         cfg.n_channels = n_ch

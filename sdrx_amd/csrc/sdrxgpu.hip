@@ -846,7 +846,15 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
     // channel list (how many channels found their conjugate partner decides the slot count), comes out under 0.97 of the pair
     // kernel's -- decided further down, once the partners are known; tuning.matrix_pipe overrides.  Its input rows start
     // T1 - M1 samples in front of a body.
-    const sdrxgpu_tuning tune0 = cfg->tuning ? *cfg->tuning : sdrxgpu_tuning{};
+    sdrxgpu_tuning tune0 = cfg->tuning ? *cfg->tuning : sdrxgpu_tuning{};
+    if (cfg->flags & SDRXGPU_FLAG_REFERENCE_ORDER) {
+        if (tune0.matrix_pipe >= 2 || (cfg->flags & SDRXGPU_FLAG_FUSED_STAGE3)) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: SDRXGPU_FLAG_REFERENCE_ORDER excludes the matrix-pipe kernels (tuning.matrix_pipe = %u, "
+                        "SDRXGPU_FLAG_FUSED_STAGE3 %s)", tune0.matrix_pipe, (cfg->flags & SDRXGPU_FLAG_FUSED_STAGE3) ? "set" : "not set");
+        }
+        tune0.matrix_pipe = 1;
+    }
     {
         const bool can = k12->M1 == 5 && k12->T1 == 17 && k12->M2 == 5 && k12->T2 == 19 && k12->Y2B == 4 && N > 0 && (N % 2) == 0;
         // ... and k_stage123m (stages 2-3 in the same kernel, k_tail_c behind it): the whole 10 MS/s chain with N = 1 200, whole

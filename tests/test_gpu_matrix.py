@@ -254,3 +254,35 @@ def test_200_blocks_in_ragged_calls_through_the_matrix_pipe(oracle):
         worst_iq, worst_au = max(worst_iq, last_iq), max(worst_au, last_au)
     margin("long_stream_200_blocks[matrix_pipe]", worst_iq=worst_iq, worst_audio=worst_au, last_block_iq=last_iq, last_block_audio=last_au)
     assert worst_iq <= RTOL and worst_au <= RTOL
+
+
+def test_reference_order_flag_keeps_a_paired_bank_on_the_vector_kernels():
+    """SDRXGPU_FLAG_REFERENCE_ORDER: what an application sets to get only the kernels that add every FIR in the reference's own
+    order (msd.hpp:309-331) -- the bank that would take the matrix pipe by itself stays on the vector kernels, bit-identical to
+    tuning.matrix_pipe = 1, also cut over devices; asking for the matrix pipe at the same time is refused."""
+    ch = chains.chain("10")
+    offs = chains.offsets_for_config("c3")
+    tabs = sb.translators_for(ch, offs)
+    x = synth.synth_iq(3, 0, ch.block_len, 0.25, [tabs[5]], [0.3], ch.N, 10000)
+    auto = sb.ChannelBank(tabs, ch.stage_tuples())
+    assert auto.info().matrix_pipe == 1
+    auto.close()
+    strict = sb.ChannelBank(tabs, ch.stage_tuples(), reference_order=True)
+    assert strict.info().matrix_pipe == 0
+    a = strict.process(x)
+    strict.close()
+    vec = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": 1})
+    b = vec.process(x)
+    vec.close()
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    mb = sb.MultiChannelBank(tabs, ch.stage_tuples(), devices=(0, 0), reference_order=True)
+    assert mb.info().matrix_pipe == 0
+    c = mb.process(x)
+    mb.close()
+    assert np.array_equal(a[0].view(np.uint32), c[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), c[1].view(np.uint32))
+    with pytest.raises(sb.SdrxGpuError) as e:
+        sb.ChannelBank(tabs, ch.stage_tuples(), reference_order=True, tuning={"matrix_pipe": 2})
+    assert e.value.code == -1
+    with pytest.raises(sb.SdrxGpuError) as e:
+        sb.ChannelBank(tabs, ch.stage_tuples(), reference_order=True, fused_stage3=True)
+    assert e.value.code == -1

@@ -61,20 +61,31 @@ def test_pair_under_a_strong_carrier(name):
     tabs = [g["tables"][i] if o != 0 else None for i, o in enumerate(offs)]
     rec = {"case": name, "A": g["meta"]["A"], "noise": g["meta"]["noise_amp"], "variant": g["meta"]["variant"], "offsets": offs}
     worst = {}
+    nearer = {}
     for path, mp in (("fused", 3), ("matrix", 2), ("vector", 1)):
         iq, au = _run(ch, tabs, blocks, mp)
         e_iq = [rel_err(iq[i], g["iq"][i]) for i in range(len(offs))]
         e_au = [rel_err(au[i], g["audio_lf"][i]) for i in range(len(offs))]
         rec[path + "_vs_ref_iq"], rec[path + "_vs_ref_audio"] = e_iq, e_au
         worst[path] = (max(e_iq), max(e_au))
+        # the fourth number (round 5): per channel the distance to the NEARER of the reference's two builds -- the portable one and
+        # the Release one (AVX2 + FMA: what sdrx ships, CMakeLists.txt:26-28,107), whose outputs the fixtures now hold too
+        n_iq = [min(a, rel_err(iq[i], g["avx2_iq"][i])) for i, a in enumerate(e_iq)]
+        n_au = [min(a, rel_err(au[i], g["avx2_audio_lf"][i])) for i, a in enumerate(e_au)]
+        rec[path + "_vs_nearer_build_iq"], rec[path + "_vs_nearer_build_audio"] = n_iq, n_au
+        rec[path + "_vs_avx2_build_iq"] = [rel_err(iq[i], g["avx2_iq"][i]) for i in range(len(offs))]
+        rec[path + "_vs_avx2_build_audio"] = [rel_err(au[i], g["avx2_audio_lf"][i]) for i in range(len(offs))]
+        nearer[path] = (max(n_iq), max(n_au))
     rec["ref_avx2_vs_portable_iq"] = [float(v) for v in g["avx2_rel_dev_iq"]]
     rec["ref_avx2_vs_portable_audio"] = [float(v) for v in g["avx2_rel_dev_audio_lf"]]
     a_iq, a_au = max(rec["ref_avx2_vs_portable_iq"]), max(rec["ref_avx2_vs_portable_audio"])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r04_parity_pairs.jsonl"), "a") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r05_parity_pairs.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     margin(f"pairs[{name}]", fused_iq=worst["fused"][0], fused_audio=worst["fused"][1], matrix_iq=worst["matrix"][0], matrix_audio=worst["matrix"][1],
-           vector_iq=worst["vector"][0], vector_audio=worst["vector"][1], ref_avx2_iq=a_iq, ref_avx2_audio=a_au)
+           vector_iq=worst["vector"][0], vector_audio=worst["vector"][1], ref_avx2_iq=a_iq, ref_avx2_audio=a_au,
+           matrix_nearer_iq=nearer["matrix"][0], matrix_nearer_audio=nearer["matrix"][1],
+           vector_nearer_iq=nearer["vector"][0], vector_nearer_audio=nearer["vector"][1])
     for path, times in (("vector", VECTOR_VS_AVX2), ("matrix", MATRIX_VS_AVX2), ("fused", FUSED_VS_AVX2)):
         for got, spread in ((worst[path][0], a_iq), (worst[path][1], a_au)):
             assert got <= max(RTOL, times * spread), (path, got, spread)
