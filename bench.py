@@ -439,7 +439,7 @@ def run_c5(args, plan, ch, rank, local_rank, world, dist, torch, np, sb, sdist, 
     banks, hosts, outs, expect = [], [], [], []
     for offs, seed in zip(plan.offsets, plan.seeds):
         tabs = sb.translators_for(ch, offs)
-        banks.append(sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank))
+        banks.append(sb.ChannelBank(tabs, ch.stage_tuples(), device=local_rank, tuning=args.tuning))
         blocks = [synth.synth_iq(seed, b * L, L, 0.25).view(np.float32).reshape(L, 2).copy() for b in range(n_host)]
         expect.append([sdist.block_checksum(b_) for b_ in blocks])
         hosts.append([torch.from_numpy(b_).pin_memory() for b_ in blocks])
@@ -662,6 +662,10 @@ def main():
 
     ch = chains.chain(args.rate)
     plan = sdist.plan(args.config, rank, world, ch.N, args.channels)
+    args.tuning = None
+    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile or args.tail_agc or args.tail_agc_cpg:
+        args.tuning = {"fused_tail": args.fused, "pair_lanes": args.pair, "matrix_pipe": args.matrix, "m_slot_groups": args.mgs, "m_seg_groups": args.mgt,
+                       "tail_tile": args.tail_tile, "tail_agc": args.tail_agc, "tail_agc_cpg": args.tail_agc_cpg}
     if plan.name == "c5":
         run_c5(args, plan, ch, rank, local_rank, world, dist, torch, np, sb, sdist, synth)       # does not return
     n_ch = plan.channels_per_gpu
@@ -705,10 +709,7 @@ def main():
     elif rank == 0:
         ring = torch.from_numpy(host).cuda()
 
-    tuning = None
-    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile or args.tail_agc or args.tail_agc_cpg:
-        tuning = {"fused_tail": args.fused, "pair_lanes": args.pair, "matrix_pipe": args.matrix, "m_slot_groups": args.mgs, "m_seg_groups": args.mgt,
-                  "tail_tile": args.tail_tile, "tail_agc": args.tail_agc, "tail_agc_cpg": args.tail_agc_cpg}
+    tuning = args.tuning
     fused_seen = {}
     pair_seen = {}
     matrix_seen = {}

@@ -21,7 +21,8 @@
  *
  * Threading: a bank is driven by one thread at a time (data_cb is never re-entered,
  * sdrx.cpp:306); different banks may be driven concurrently from different threads, each
- * on its own HIP stream.  There is no global mutable state outside banks.
+ * on its own HIP stream.  There is no global mutable state outside banks but a count of the
+ * banks alive per device (it picks between two kernel sequences that give the same bits).
  *
  * Errors: every function returns 0 on success or a negative SDRXGPU_ERR_* code, in the
  * style of the reference's device layer (src/r820_dev.hpp:61-72).  There is NO CPU fallback:
@@ -148,9 +149,10 @@ typedef struct {
     uint32_t m_seg_groups;   /*   pairs x 16 time segments: (2,2), (4,2) or (2,4); 0 = auto                        */
     uint32_t tail_agc;       /* the remaining decimator stage(s) and the AGC / demodulator as ONE kernel (k_tail_agc: tiles of 32
                                 outputs handed from producer waves to the AGC waves through LDS; same bits as k_tail_s + k_agc):
-                                0 = auto = 1 = never (measured slower than the two kernels at every bank size),
-                                2 = require                                                                            */
-    uint32_t tail_agc_cpg;   /*   channels per workgroup of that kernel, 1..16; 0 = auto                               */
+                                0 = auto (banks of 256 .. 1 024 channels on the separate tail: 1 to 5 % less time per block; below,
+                                the two kernels' own latency chains are shorter than its pipeline's fill, above, its workgroups
+                                no longer fit the chip at once: DESIGN.md 4.10), 1 = never, 2 = require                  */
+    uint32_t tail_agc_cpg;   /*   channels per workgroup of that kernel: 1, 2 or 4; 0 = auto                           */
 } sdrxgpu_tuning;
 
 typedef struct {

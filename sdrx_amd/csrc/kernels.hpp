@@ -227,6 +227,12 @@ __device__ __forceinline__ v2f folded_fir_ahead(const v2f *__restrict__ w, const
     return acc;
 }
 
+// folded_fir_ahead for TWO windows at once (k_tail_agc's producer waves, alone on their SIMD: two independent accumulation chains
+// instead of one halve the time a wave spends waiting for its own previous instruction).  Per output the same operands in the same
+// order as folded_fir_ahead / folded_fir_unrolled: same bits.  (Defined below fma_tap2.)
+template <int T, int NH, int D>
+__device__ __forceinline__ void folded_fir2_ahead(v2f &r0, v2f &r1, const v2f *__restrict__ w0, const v2f *__restrict__ w1, const float (&h)[NH]);
+
 // Two outputs at once (windows w0 and w1, same taps): the two accumulation chains alternate, so neither packed FMA
 // reads the result of the instruction before it and one wait state serves both (fma_tap spends one per tap).  Per
 // output the same instruction sequence on the same operands as folded_fir_unrolled: bit-identical results.
@@ -239,6 +245,46 @@ __device__ __forceinline__ void fma_tap2(v2f &acc0, v2f &acc1, const v2f x0, con
     else
         asm("s_nop 0\n\tv_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
             : "+v"(acc0), "+v"(acc1) : "v"(x0), "v"(x1), "s"(hpair));
+}
+
+template <int T, int NH, int D, int I = 0>
+__device__ __forceinline__ void folded_fir2_ahead_steps(v2f &acc0, v2f &acc1, v2f (&lo0)[D], v2f (&hi0)[D], v2f (&lo1)[D], v2f (&hi1)[D],
+                                                        const v2f *__restrict__ w0, const v2f *__restrict__ w1, const float (&h)[NH])
+{
+    constexpr int half = (T - 1) >> 1;
+    if constexpr (I <= half) {
+        const v2f hp = {h[I & ~1], h[(I & ~1) + 1]};
+        if constexpr (I < half) {
+            const v2f s0 = lo0[I % D] + hi0[I % D], s1 = lo1[I % D] + hi1[I % D];
+            if constexpr (I + D < half) {
+                lo0[I % D] = lds_read_here(w0 + I + D); hi0[I % D] = lds_read_here(w0 + T - 1 - I - D);
+                lo1[I % D] = lds_read_here(w1 + I + D); hi1[I % D] = lds_read_here(w1 + T - 1 - I - D);
+            } else if constexpr (I + D == half) {
+                lo0[I % D] = lds_read_here(w0 + half);
+                lo1[I % D] = lds_read_here(w1 + half);
+            }
+            fma_tap2<I>(acc0, acc1, s0, s1, hp);
+        } else {
+            fma_tap2<I>(acc0, acc1, lo0[I % D], lo1[I % D], hp);
+        }
+        folded_fir2_ahead_steps<T, NH, D, I + 1>(acc0, acc1, lo0, hi0, lo1, hi1, w0, w1, h);
+    }
+}
+
+template <int T, int NH, int D>
+__device__ __forceinline__ void folded_fir2_ahead(v2f &r0, v2f &r1, const v2f *__restrict__ w0, const v2f *__restrict__ w1, const float (&h)[NH])
+{
+    constexpr int half = (T - 1) >> 1;
+    static_assert(D >= 1 && D <= half, "prefetch distance in tap pairs");
+    v2f lo0[D], hi0[D], lo1[D], hi1[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        lo0[i] = lds_read_here(w0 + i); hi0[i] = lds_read_here(w0 + T - 1 - i);
+        lo1[i] = lds_read_here(w1 + i); hi1[i] = lds_read_here(w1 + T - 1 - i);
+    }
+    r0 = v2f{0.f, 0.f};
+    r1 = v2f{0.f, 0.f};
+    folded_fir2_ahead_steps<T, NH, D>(r0, r1, lo0, hi0, lo1, hi1, w0, w1, h);
 }
 
 template <int T, int NH, int I = 0>
@@ -1653,6 +1699,9 @@ __global__ __launch_bounds__(4 * kWave) void k_agc(const AgcArgs a)
         }
     } else if (wave == 0) {
         // ---- IF AGC ----
+#ifdef SDRX_LAB_AGC_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         const float4 s4 = a.state[ch];
         float g = s4.x, pw = s4.y;
         __syncthreads();
@@ -1688,6 +1737,9 @@ __global__ __launch_bounds__(4 * kWave) void k_agc(const AgcArgs a)
         if (ok) reinterpret_cast<float2 *>(a.state + ch)[0] = make_float2(g, pw);
     } else if (wave == 1) {
         // ---- envelope / FM phase step -> LF AGC -> squelch gating, one tile behind wave 0 ----
+#ifdef SDRX_LAB_AGC_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         const float4 s4 = a.state[ch];
         float gl = s4.z, pl = s4.w;
         bool is_fm = false;

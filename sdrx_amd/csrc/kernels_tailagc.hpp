@@ -6,19 +6,12 @@
 // sdrx.cpp:178-194, LfAGC::adjust agc.hpp:106-131) -- in the reference these run back to back per sample with nothing in
 // between; k_tail_s + k_agc put a launch boundary and a round trip through d_keep between them.
 //
-// Why: the AGC is the path's one true recurrence -- 512 dependent steps per channel and block, ~54 ns each at the instruction
-// latency floor = 27.6 us whatever the bank's size -- and for banks of up to a few thousand channels the tail in
-// front of it is a latency chain too (one tile round trip per workgroup: 24 us at 1 024 channels, 7 us at 64).  As two kernels
-// the two chains ADD (0.052 of the 1 024-channel block's 0.130 ms).  Here a workgroup owns `cpg` channels; NT tail waves
-// produce their stage-4 outputs tile by tile in TIME order (32 outputs per tile, the tile's stage-2 span prefetched in
-// registers while the previous unit is computed) and hand each tile to the AGC waves through LDS, which are by then running
-// the previous tile's 32 serial steps:
-//   waves 0..NT-1  tail producers: unit = (channel, tile); [stage-2 span -> LDS] -> stage A -> stage B -> iq_out / iq_keep and the
-//                  tile buffer xa (time-major, lane = channel for the consumer).  Wave-private LDS, no barrier inside a unit.
-//   wave NT        IF AGC on tile i-1, lane = channel, publishes |y|^2 (FM: and y) through LDS
-//   wave NT+1      tile i-2: envelope / FM phase step, LF AGC, squelch gating -> audio rows (16-byte stores, 4 samples per lane)
-// One workgroup barrier per tile.  The chain's length stays (16 + 2 tiles x 1.73 us); what goes is the tail's own chain, the
-// launch boundary and the d_keep round trip.
+// Why: the AGC is the path's one true recurrence -- 512 dependent steps per channel and block at the instruction latency floor
+// (DESIGN 4.6): 27.6 us as k_agc, whatever the bank's size -- and for banks of up to a thousand channels the tail in front of it is
+// a latency chain too (one tile round trip per workgroup: 24 us at 1 024 channels, 7 us at 64).  As two kernels the two chains ADD.
+// Here a workgroup owns NC channels, and per channel two producer waves hand tiles of 32 outputs, in TIME order, through LDS to
+// the AGC waves, which are by then running the previous tiles' serial steps (the iteration scheme is at the kernel).  The chain's
+// length stays; what goes is the tail's own chain, the launch boundary and the d_keep round trip.
 // EVERY value is computed by the same functions on the same operands as in k_tail_s (tail_s_unit: folded_fir_ahead in the
 // reference's order) and k_agc (if_agc_step / demod_lf_step): outputs are bit-identical to the two-kernel sequence (tested,
 // tests/test_gpu_tailagc.py), so which of the two a bank runs is a geometry choice like any other of sdrxgpu_tuning.
@@ -34,6 +27,8 @@ struct TailAgcArgs {
     AgcArgs g;                         // as for k_agc; iq / iq_stride are not used (the tiles come through LDS)
     int cpg;                           // channels per workgroup, 1 .. kTaMaxCpg
     int n_groups;                      // groups of y2b stage-2 outputs this call has: entries of the index table in LDS
+    const uint32_t *gtab;              // [>= n_groups] where group g of a call's stage-2 outputs lies in a channel's scratch row (the
+                                       //   bank's geometry: built once on the host at bank_create, copied to LDS per workgroup)
 };
 
 template <int MA, int TA, int MB, int TB>
@@ -42,24 +37,24 @@ struct TailAgcGeom {
     static constexpr int NR = HAS_A ? MB * (kAgcTile - 1) + TB : 0;                          // stage-A outputs under a full tile
     static constexpr int NP = HAS_A ? MA * (NR - 1) + TA : MB * (kAgcTile - 1) + TB;         // stage-2 row entries under it
     static constexpr int NPAIR = (NP + 3 + 1) / 2;                                           // 16-byte pairs incl. the lead (<= 3 entries)
-    static constexpr int RD = (NPAIR + kWave - 1) / kWave;                                   // LDS-DMA instructions per unit
+    static constexpr int RD = (NPAIR + kWave - 1) / kWave;                                   // LDS-DMA instructions per tile
     static constexpr int S2N = RD * kWave * 2;                                               // span entries of one buffer
-    static constexpr int S3N = (NR + 1) & ~1;
-    static constexpr int NBUF = 3;                                                           // the spans of units u, u+1, u+2
-    static constexpr size_t wave_lds = (size_t)(NBUF * S2N + S3N) * sizeof(float2);
+    static constexpr int S3N = HAS_A ? ((NR + 1) & ~1) : 0;
+    static constexpr int NBUF = HAS_A ? 3 : 4;      // span ring: tiles k (read by the A-wave), k+1, k+2 -- and k-1 where the B-wave reads spans itself
+    static constexpr size_t chan_lds = (size_t)(NBUF * S2N + 2 * S3N) * sizeof(float2);     // per channel: span ring + two stage-A buffers
 };
 
-template <bool FM>
+template <bool FM, int NC>
 struct TailAgcLds {
-    float2 xa[2][kAgcTile][kTaMaxCpg];                 // tail -> IF wave: stage-4 outputs, [sample][channel]
-    float ex[2][kAgcTile][FM ? 3 : 1][kTaMaxCpg];      // IF wave -> LF wave
+    float2 xa[2][kAgcTile][NC];                        // B-wave -> IF wave: stage-4 outputs, [sample][channel]
+    float ex[2][kAgcTile][FM ? 3 : 1][NC];             // IF wave -> LF wave
 };
 
-// (+ the index table: one 32-bit entry per group of y2b stage-2 outputs of the call, behind the producers' buffers)
-template <int MA, int TA, int MB, int TB, bool FM, int NT>
+// (+ the index table: one 32-bit entry per group of y2b stage-2 outputs of the call, behind the channels' buffers)
+template <int MA, int TA, int MB, int TB, bool FM, int NC>
 constexpr size_t tail_agc_lds_bytes()
 {
-    return sizeof(TailAgcLds<FM>) + NT * TailAgcGeom<MA, TA, MB, TB>::wave_lds;
+    return sizeof(TailAgcLds<FM, NC>) + NC * TailAgcGeom<MA, TA, MB, TB>::chan_lds;
 }
 
 // within ONE wave: what its lanes wrote to LDS is visible to its other lanes (LDS serves a wave's instructions in order); this
@@ -72,151 +67,161 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // The workgroup's barrier per tile, ordering LDS only: __syncthreads() is a release + acquire of GLOBAL memory as well, i.e.
-// s_waitcnt vmcnt(0) -- every producer wave would wait there for the spans it has just asked for (two units ahead), and the
-// prefetch would be worth nothing.  What the waves hand each other goes through LDS; what they write to global memory nobody
-// in this kernel reads.
-// (Not even a fence of the LDS address space alone will do for the producers: their LDS-DMAs ARE pending LDS writes to the
-// compiler, and a release waits for them.  So: the wave's own ds_ instructions done -- lgkmcnt(0) --, then the raw barrier; the
-// "memory" clobber keeps the compiler from moving any access across.  The spans in flight are waited for where they are
-// needed, by count.)
+// s_waitcnt vmcnt(0) -- a wave would wait there for the spans it has just asked for (two tiles ahead), and the prefetch would be
+// worth nothing.  Not even a fence of the LDS address space alone will do: LDS-DMAs ARE pending LDS writes to the compiler, and
+// a release waits for them.  So: the wave's own ds_ instructions done -- lgkmcnt(0) --, then the raw barrier; the "memory"
+// clobber keeps the compiler from moving any access across.  The spans in flight are waited for where they are needed, by count.
+// (What the waves hand each other goes through LDS; what they write to global memory nobody in this kernel reads.)
 __device__ __forceinline__ void wg_barrier_lds()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MA, int TA, int MB, int TB, bool SQ, bool FM, int NT>
-__global__ __launch_bounds__((NT + 2) * kWave) void k_tail_agc(const TailAgcArgs a)
+// NC channels per workgroup; waves: [0, NC) A-waves (stage A of their channel), [NC, 2 NC) B-waves (LDS-DMA of the spans, stage B,
+// outputs), 2 NC the IF-AGC wave, 2 NC + 1 the LF wave.  Iteration k (one workgroup barrier each):
+//   B-wave   asks for the span of tile k+2 (LDS-DMA into ring buffer (k+2) % 3 -- free since the A-wave read tile k-1 there an
+//            iteration ago), runs stage B of tile k-1 from the stage-A buffer (k-1) & 1 -> iq_out / iq_keep / xa[(k-1) & 1], then
+//            waits until the span of tile k+1 (asked for an iteration ago) has landed: the A-wave reads it after the barrier
+//   A-wave   stage A of tile k: span ring k % 3 -> stage-A buffer k & 1
+//   IF wave  tile k-2;  LF wave  tile k-3
+template <int MA, int TA, int MB, int TB, bool SQ, bool FM, int NC>
+__global__ __launch_bounds__((2 * NC + 2) * kWave) void k_tail_agc(const TailAgcArgs a)
 {
     using G = TailAgcGeom<MA, TA, MB, TB>;
     constexpr bool HAS_A = G::HAS_A;
+    constexpr int NTHREADS = (2 * NC + 2) * kWave;
     extern __shared__ __attribute__((aligned(16))) char ta_smem[];
-    TailAgcLds<FM> &L = *reinterpret_cast<TailAgcLds<FM> *>(ta_smem);
+    TailAgcLds<FM, NC> &L = *reinterpret_cast<TailAgcLds<FM, NC> *>(ta_smem);
     const TailArgs &t = a.t;
     const AgcArgs &g = a.g;
 
     // one extra block copies the input history to the front of the other input ring for the next call (as in k_agc)
     if (g.roll_cnt > 0 && blockIdx.x == gridDim.x - 1) {
-        for (int i = threadIdx.x; i < g.roll_cnt; i += (NT + 2) * kWave) g.roll_to[i] = g.roll_from[i];
+        for (int i = threadIdx.x; i < g.roll_cnt; i += NTHREADS) g.roll_to[i] = g.roll_from[i];
         return;
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & (kWave - 1);
-    const int ch0 = t.ch_lo + blockIdx.x * a.cpg;
-    const int n_here = min(a.cpg, t.n_ch - ch0);                    // channels of this workgroup (>= 1)
+    const int ch0 = t.ch_lo + blockIdx.x * NC;
+    const int n_here = min(NC, t.n_ch - ch0);                       // channels of this workgroup (>= 1)
     const int n_b = t.n_b;
     const int n_tiles = (n_b + kAgcTile - 1) / kAgcTile;
+    const int n_iter = n_tiles + 3;
 
-    // Where the stage-1/2 kernel left group g of this call's stage-2 outputs (body-major scratch, any layout): worked out once
-    // per workgroup, by everybody, into a table in LDS.  Per DMA instruction and lane the arithmetic of y2_group_index -- three
-    // divisions by float reciprocal and the layout's branches, ~100 instructions -- was two thirds of a producer wave's work.
-    uint32_t *gtab = reinterpret_cast<uint32_t *>(ta_smem + tail_agc_lds_bytes<MA, TA, MB, TB, FM, NT>());
-    for (int gi = threadIdx.x; gi < a.n_groups; gi += (NT + 2) * kWave) gtab[gi] = (uint32_t)y2_group_index(t, gi << t.y2b_shift);
+    // Where the stage-1/2 kernel left group g of a call's stage-2 outputs in a channel's scratch row (body-major, any layout): the
+    // bank's geometry only, so the host builds the table once at bank_create and a workgroup copies it into LDS.  (Worked out per
+    // DMA instruction and lane -- y2_group_index: three divisions by float reciprocal and the layout's branches, ~100 instructions --
+    // it was two thirds of a producer wave's work; worked out per workgroup it cost 4.5 us of start-up.)
+    uint32_t *gtab = reinterpret_cast<uint32_t *>(ta_smem + tail_agc_lds_bytes<MA, TA, MB, TB, FM, NC>());
+    for (int gi = threadIdx.x * 4; gi < a.n_groups; gi += NTHREADS * 4)                  // (the table is padded to whole 16-byte pieces)
+        *reinterpret_cast<uint4 *>(gtab + gi) = *reinterpret_cast<const uint4 *>(a.gtab + gi);
     __syncthreads();
 
-    if (wave < NT) {
-        // ------------------------------------------------------------------------------------------------------------
-        // tail producer: units (tile i, channel ch0 + wave + NT * j), tile-major
-        // ------------------------------------------------------------------------------------------------------------
-        float2 *smem = reinterpret_cast<float2 *>(ta_smem + sizeof(TailAgcLds<FM>) + (size_t)wave * G::wave_lds);
-        const int n_mine = wave < n_here ? (n_here - wave + NT - 1) / NT : 0;
-        const int Gsz = t.y2b, gsh = t.y2b_shift;
-        const int n_row = t.hist + t.n_y2_new;
-        const int p_last = (n_row - 1) & ~(Gsz - 1);
-
-        // history for the next call = the last `hist` entries of the row [hist | new] (tail_s_unit's last tile does this)
-        for (int j = 0; j < n_mine; j++) {
-            const int ch = ch0 + wave + NT * j;
-            const float2 *__restrict__ ynew = t.y2_new + (size_t)ch * t.y2_stride;
-            const float2 *__restrict__ hin = t.hist_in + (size_t)ch * t.hist;
-            float2 *__restrict__ hout = t.hist_out + (size_t)ch * t.hist;
-            for (int i = lane; i < t.hist; i += kWave) {
-                const int idx = t.n_y2_new + i;
-                hout[i] = idx < t.hist ? hin[idx] : ynew[y2_storage_index(t, idx - t.hist)];
-            }
+    const int Gsz = t.y2b, gsh = t.y2b_shift;
+    // span of tile i: outputs, stage-A outputs, first row entry (group-aligned) and the lead in front of the window
+    auto span = [&](int i, int &nbt, int &nr, int &p0g, int &lead) {
+        const int s0 = i * kAgcTile;
+        nbt = min(n_b - s0, kAgcTile);
+        int p0;
+        if constexpr (HAS_A) {
+            const int r0 = t.pB0 + MB * s0;
+            nr = MB * (nbt - 1) + TB;
+            p0 = t.pA0 + MA * r0;
+        } else {
+            nr = 0;
+            p0 = t.pB0 + MB * s0;
         }
+        p0g = p0 & ~(Gsz - 1);
+        lead = p0 - p0g;
+    };
 
-        // span of unit (tile i): outputs, stage-A outputs, first row entry (group-aligned) and the lead in front of the window
-        auto span = [&](int i, int &nbt, int &nr, int &p0g, int &lead) {
-            const int s0 = i * kAgcTile;
-            nbt = min(n_b - s0, kAgcTile);
-            int p0;
-            if constexpr (HAS_A) {
-                const int r0 = t.pB0 + MB * s0;
-                nr = MB * (nbt - 1) + TB;
-                p0 = t.pA0 + MA * r0;
-            } else {
-                nr = 0;
-                p0 = t.pB0 + MB * s0;
+    if (wave < 2 * NC) {
+        const bool is_b = wave >= NC;
+        const int cl = is_b ? wave - NC : wave;                     // channel within the workgroup
+        const bool live = cl < n_here;
+        const int ch = ch0 + min(cl, n_here - 1);
+        float2 *cbase = reinterpret_cast<float2 *>(ta_smem + sizeof(TailAgcLds<FM, NC>) + (size_t)cl * G::chan_lds);
+        float2 *s3base = cbase + G::NBUF * G::S2N;
+        if (!is_b) {
+            // --------------------------------------------------------------------------------------------------------
+            // A-wave: stage A of tile k in iteration k
+            // --------------------------------------------------------------------------------------------------------
+            wg_barrier_lds();
+            for (int k = 0; k < n_iter; k++) {
+                if constexpr (HAS_A) {
+                    if (live && k < n_tiles) {
+                        int nbt, nr, p0g, lead;
+                        span(k, nbt, nr, p0g, lead);
+                        const v2f *s2 = reinterpret_cast<const v2f *>(cbase + (k % G::NBUF) * G::S2N) + lead;
+                        v2f *s3 = reinterpret_cast<v2f *>(s3base + (k & 1) * G::S3N);
+#ifndef SDRX_LAB_TA_NOFIR
+                        // two outputs per lane and pass (r and r + 64: two independent accumulation chains -- the wave is alone on its
+                        // SIMD, nothing else fills the wait between two dependent instructions); per output folded_fir_ahead's arithmetic
+                        for (int r = lane; r < nr; r += 2 * kWave) {
+                            const int r1 = min(r + kWave, nr - 1);                 // (past the end: the last output once more, not stored)
+                            v2f o0, o1;
+                            folded_fir2_ahead<TA, kMaxHalfTaps, SDRX_FIR_AHEAD_A>(o0, o1, s2 + MA * r, s2 + MA * r1, t.hA);
+                            s3[r] = o0;
+                            if (r + kWave < nr) s3[r + kWave] = o1;
+                        }
+#endif
+                    }
+                }
+                wg_barrier_lds();
             }
-            p0g = p0 & ~(Gsz - 1);
-            lead = p0 - p0g;
-        };
-        // The span of a unit goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, nothing waits): lane l of
-        // instruction r moves the 16-byte pair q = 64 r + l of the span -- row entries p0g + 2 q, + 1 -- from wherever the
-        // body-major scratch (or the history) keeps it to s2[2 q], so the span lands in TIME order.  A pair past the end of
-        // the row re-reads the last pair (never inside a FIR window).  (First version: 16-byte loads into registers, written
-        // to LDS a unit later -- 40 registers, two of them spilled, and a spilled load is a load that is waited for at once:
-        // 59 us for the kernel where the chain is 30.)
-        const int p_lastpair = (n_row - 1) & ~1;
-        const int pair2 = t.half_split ? 2 * t.spw : 2;
-        auto issue = [&](int ch, int p0g, int buf) {
+        } else {
+            // --------------------------------------------------------------------------------------------------------
+            // B-wave: spans in (LDS-DMA), stage B of tile k-1 in iteration k, outputs, the tile for the AGC waves
+            // --------------------------------------------------------------------------------------------------------
             const float2 *__restrict__ ynew = t.y2_new + (size_t)ch * t.y2_stride;
             const float2 *__restrict__ hin = t.hist_in + (size_t)ch * t.hist;
-            char *dst = reinterpret_cast<char *>(smem + buf * G::S2N);
-            // all source addresses first, then the DMA instructions back to back (address arithmetic between two of them made the
-            // compiler wait for the first before it let the second go)
-            uintptr_t src[G::RD];
+            const int n_row = t.hist + t.n_y2_new;
+            const int p_lastpair = (n_row - 1) & ~1;
+            const int pair2 = t.half_split ? 2 * t.spw : 2;
+            // The span of a tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, nothing waits): lane l of
+            // instruction r moves the 16-byte pair q = 64 r + l of the span -- row entries p0g + 2 q, + 1 -- from wherever the
+            // body-major scratch (or the history) keeps it to s2[2 q], so the span lands in TIME order.  A pair past the end of
+            // the row re-reads the last pair (never inside a FIR window).  All source addresses first, then the DMA
+            // instructions back to back (address arithmetic between two of them made the compiler wait for the first before it
+            // let the second go).
+            auto issue_tile = [&](int i) {
+                if (!live || i >= n_tiles) return;
+                int nbt, nr, p0g, lead;
+                span(i, nbt, nr, p0g, lead);
+                char *dst = reinterpret_cast<char *>(cbase + (i % G::NBUF) * G::S2N);
+                uintptr_t src[G::RD];
 #pragma unroll
-            for (int r = 0; r < G::RD; r++) {
-                const int p = min(p0g + 2 * (lane + kWave * r), p_lastpair);
-                const int j = max(p - t.hist, 0);
-                // (the group's second pair: the next two entries, or -- half_split -- one half-body row further)
-                const int off2 = (Gsz == 4 && (j & 2)) ? pair2 : 0;
-                const int e_new = (int)gtab[j >> gsh] + off2;
-                const bool in_hist = p < t.hist;
-                src[r] = (uintptr_t)((in_hist ? hin : ynew) + (in_hist ? p : e_new));
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < G::RD; r++) {
+                    const int p = min(p0g + 2 * (lane + kWave * r), p_lastpair);
+                    const int j = max(p - t.hist, 0);
+                    // (the group's second pair: the next two entries, or -- half_split -- one half-body row further)
+                    const int off2 = (Gsz == 4 && (j & 2)) ? pair2 : 0;
+                    const int e_new = (int)gtab[j >> gsh] + off2;
+                    const bool in_hist = p < t.hist;
+                    src[r] = (uintptr_t)((in_hist ? hin : ynew) + (in_hist ? p : e_new));
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < G::RD; r++)
-                __builtin_amdgcn_global_load_lds((gbl_void *)src[r], (lds_void *)(uint32_t)(uintptr_t)(dst + r * kWave * 16), 16, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // my units in order: u = i * n_mine + j  <->  (tile i, channel ch0 + wave + NT * j)
-        const int n_units = n_mine * n_tiles;
-        auto issue_unit = [&](int u) {
-            if (u >= n_units) return;
-            const int i = u / n_mine, j = u - i * n_mine;
-            int nbt, nr, p0g, lead;
-            span(i, nbt, nr, p0g, lead);
-            issue(ch0 + wave + NT * j, p0g, u % G::NBUF);
-        };
-        issue_unit(0);
-        issue_unit(1);
-        wg_barrier_lds();
-        int u = 0;
-        for (int i = 0; i < n_tiles + 2; i++) {
-            if (i < n_tiles) {
-                for (int j = 0; j < n_mine; j++, u++) {
-                    const int cl = wave + NT * j;                  // channel within the workgroup
-                    const int ch = ch0 + cl;
+                for (int r = 0; r < G::RD; r++)
+                    __builtin_amdgcn_global_load_lds((gbl_void *)src[r], (lds_void *)(uint32_t)(uintptr_t)(dst + r * kWave * 16), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            const int n_st = (t.iq_out ? 1 : 0) + (t.iq_keep ? 1 : 0);      // stores a tile's stage B issues
+            issue_tile(0);
+            issue_tile(1);
+            // (tile 0's span: everything but tile 1's DMAs has landed)
+            if (live && n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::RD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wg_barrier_lds();
+            for (int k = 0; k < n_iter; k++) {
+                issue_tile(k + 2);
+                const int tb = k - 1;
+                const bool has_b = live && tb >= 0 && tb < n_tiles;
+                if (has_b) {
                     int nbt, nr, p0g, lead;
-                    span(i, nbt, nr, p0g, lead);
-                    // unit u's span has landed: DMAs return in order, and the only VM instructions younger than them that may be
-                    // outstanding are unit u+1's (stores in between are older than those and only make the wait stricter)
-                    if (u + 1 < n_units) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::RD) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    wave_lds_sync();
-                    const v2f *s2 = reinterpret_cast<const v2f *>(smem + (u % G::NBUF) * G::S2N) + lead;
-                    v2f *s3 = reinterpret_cast<v2f *>(smem + G::NBUF * G::S2N);
-                    const v2f *bsrc = s2;
-                    if constexpr (HAS_A) {
-#ifndef SDRX_LAB_TA_NOFIR
-                        for (int r = lane; r < nr; r += kWave) s3[r] = folded_fir_ahead<TA, kMaxHalfTaps, SDRX_FIR_AHEAD_A>(s2 + MA * r, t.hA);
-#endif
-                        wave_lds_sync();
-                        bsrc = s3;
-                    }
+                    span(tb, nbt, nr, p0g, lead);
+                    const v2f *bsrc = HAS_A ? reinterpret_cast<const v2f *>(s3base + (tb & 1) * G::S3N)
+                                            : reinterpret_cast<const v2f *>(cbase + (tb % G::NBUF) * G::S2N) + lead;
                     if (lane < nbt) {
 #ifndef SDRX_LAB_TA_NOFIR
                         const v2f r = folded_fir_ahead<TB, kMaxHalfTaps, SDRX_FIR_AHEAD_B>(bsrc + MB * lane, t.hB);
@@ -224,23 +229,39 @@ __global__ __launch_bounds__((NT + 2) * kWave) void k_tail_agc(const TailAgcArgs
                         const v2f r = bsrc[lane];
 #endif
                         const float2 o = make_float2(r.x, r.y);
-                        const int s0 = i * kAgcTile;
+                        const int s0 = tb * kAgcTile;
                         if (t.iq_out) t.iq_out[(size_t)ch * t.out_stride + s0 + lane] = o;
                         if (t.iq_keep) t.iq_keep[(size_t)ch * t.keep_stride + s0 + lane] = o;
                         // (as an instruction of my own: a ds_write the compiler knows of makes it wait for every LDS-DMA in flight --
-                        // LDS writes that might alias --, i.e. for the span of the NEXT unit.  The barrier's lgkmcnt(0) covers it.)
-                        asm volatile("ds_write_b64 %0, %1" ::"v"((uint32_t)(uintptr_t)&L.xa[i & 1][lane][cl]), "v"(r) : "memory");
+                        // LDS writes that might alias.  The barrier's lgkmcnt(0) covers it.)
+                        asm volatile("ds_write_b64 %0, %1" ::"v"((uint32_t)(uintptr_t)&L.xa[tb & 1][lane][cl]), "v"(r) : "memory");
                     }
-                    // the buffer two units back is free (its reads are this wave's own, done): the span of unit u + 2 goes there
-                    wave_lds_sync();
-#ifndef SDRX_LAB_TA_NOLOAD
-                    issue_unit(u + 2);
-#endif
+                }
+                // The A-wave reads the span of tile k+1 after this barrier: asked for an iteration ago.  DMAs return in order; younger
+                // than that span's are only this iteration's: the DMAs of tile k+2 (if it exists) and stage B's stores.
+                {
+                    const int young = ((live && k + 2 < n_tiles) ? G::RD : 0) + (has_b ? n_st : 0);
+                    if (young >= G::RD + 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::RD + 2) : "memory");
+                    else if (young == G::RD + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::RD + 1) : "memory");
+                    else if (young == G::RD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::RD) : "memory");
+                    else if (young == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if (young == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                wg_barrier_lds();
+            }
+            // (last, off the tiles' critical path:) history for the next call = the last `hist` entries of the row [hist | new]
+            if (live) {
+                float2 *__restrict__ hout = t.hist_out + (size_t)ch * t.hist;
+                for (int i = lane; i < t.hist; i += kWave) {
+                    const int idx = t.n_y2_new + i;
+                    const int j = max(idx - t.hist, 0), q = j & (Gsz - 1);
+                    const int e = (int)gtab[j >> gsh] + ((Gsz == 4 && (q & 2)) ? pair2 : 0) + (q & 1);
+                    hout[i] = idx < t.hist ? hin[idx] : ynew[e];
                 }
             }
-            wg_barrier_lds();
         }
-    } else if (wave == NT) {
+    } else if (wave == 2 * NC) {
         // ------------------------------------------------------------------------------------------------------------
         // IF AGC (AGC::adjust), one tile behind the producers; lane = channel
         // ------------------------------------------------------------------------------------------------------------
@@ -269,8 +290,8 @@ __global__ __launch_bounds__((NT + 2) * kWave) void k_tail_agc(const TailAgcArgs
                 }
             }
         };
-        for (int i = 0; i < n_tiles + 2; i++) {
-            const int ti = i - 1;
+        for (int i = 0; i < n_iter; i++) {
+            const int ti = i - 2;
 #ifndef SDRX_LAB_TA_NOAGC
             if (ti >= 0 && ti < n_tiles) {
                 if ((ti + 1) * kAgcTile <= n_b) if_tile(ti, std::true_type{});
@@ -344,10 +365,10 @@ __global__ __launch_bounds__((NT + 2) * kWave) void k_tail_agc(const TailAgcArgs
                 }
             }
         };
-        for (int i = 0; i < n_tiles + 2; i++) {
-            const int ti = i - 2;
+        for (int i = 0; i < n_iter; i++) {
+            const int ti = i - 3;
 #ifndef SDRX_LAB_TA_NOAGC
-            if (ti >= 0) {
+            if (ti >= 0 && ti < n_tiles) {
                 if ((ti + 1) * kAgcTile <= n_b) lf_tile(ti, std::true_type{});
                 else lf_tile(ti, std::false_type{});
             }

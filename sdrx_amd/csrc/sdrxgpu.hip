@@ -411,14 +411,14 @@ static const K12Entry *find_k12(int M1, int T1, int M2, int T2)
 
 // k_tail_agc (kernels_tailagc.hpp) for the tail of a chain: the kernel and the LDS of its fixed part (the index table comes on top)
 typedef void (*TailAgcKernel)(const TailAgcArgs);
-constexpr int kTaNT = 2;                                   // producer waves per workgroup
-static bool find_tail_agc(int mA, int tA, int mB, int tB, bool sq, bool fm, TailAgcKernel *k, size_t *lds)
+template <int NT>
+static bool find_tail_agc_nt(int mA, int tA, int mB, int tB, bool sq, bool fm, TailAgcKernel *k, size_t *lds)
 {
 #define SDRX_TA_PICK(MA_, TA_, MB_, TB_)                                                                                  \
     if (mA == MA_ && tA == TA_ && mB == MB_ && tB == TB_) {                                                               \
-        *k = sq ? (fm ? &k_tail_agc<MA_, TA_, MB_, TB_, true, true, kTaNT> : &k_tail_agc<MA_, TA_, MB_, TB_, true, false, kTaNT>) \
-                : (fm ? &k_tail_agc<MA_, TA_, MB_, TB_, false, true, kTaNT> : &k_tail_agc<MA_, TA_, MB_, TB_, false, false, kTaNT>); \
-        *lds = fm ? tail_agc_lds_bytes<MA_, TA_, MB_, TB_, true, kTaNT>() : tail_agc_lds_bytes<MA_, TA_, MB_, TB_, false, kTaNT>(); \
+        *k = sq ? (fm ? &k_tail_agc<MA_, TA_, MB_, TB_, true, true, NT> : &k_tail_agc<MA_, TA_, MB_, TB_, true, false, NT>) \
+                : (fm ? &k_tail_agc<MA_, TA_, MB_, TB_, false, true, NT> : &k_tail_agc<MA_, TA_, MB_, TB_, false, false, NT>); \
+        *lds = fm ? tail_agc_lds_bytes<MA_, TA_, MB_, TB_, true, NT>() : tail_agc_lds_bytes<MA_, TA_, MB_, TB_, false, NT>(); \
         return true;                                                                                                      \
     }
     SDRX_TA_PICK(5, 21, 5, 67)     // 10 MS/s
@@ -429,13 +429,34 @@ static bool find_tail_agc(int mA, int tA, int mB, int tB, bool sq, bool fm, Tail
 #undef SDRX_TA_PICK
     return false;
 }
+// nt: producer waves per workgroup (1, 2 or 4)
+static bool find_tail_agc(int nt, int mA, int tA, int mB, int tB, bool sq, bool fm, TailAgcKernel *k, size_t *lds)
+{
+    if (nt == 1) return find_tail_agc_nt<1>(mA, tA, mB, tB, sq, fm, k, lds);
+    if (nt == 2) return find_tail_agc_nt<2>(mA, tA, mB, tB, sq, fm, k, lds);
+    if (nt == 4) return find_tail_agc_nt<4>(mA, tA, mB, tB, sq, fm, k, lds);
+    return false;
+}
 
 static long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) : a; }
 
-// largest bank (channels) that takes k_tail_agc automatically: none -- measured slower than k_tail_s + k_agc at every size
-// (64 channels 44 against 34 us, 1 024: 71 against 52), so it is a caller's choice (lab builds: -DSDRX_TAILAGC_AUTO_MAX=...)
-#ifndef SDRX_TAILAGC_AUTO_MAX
-#define SDRX_TAILAGC_AUTO_MAX 0
+// Banks alive per device.  The one thing it decides is a launch-time choice between two bit-identical kernel sequences
+// (k_tail_agc or k_tail_s + k_agc, launch_tail): a bank ALONE on its GPU is 4 % faster per block with the fused kernel, two banks
+// sharing a GPU (BASELINE configs[4]) are 12 % slower with it -- its long-lived workgroups get in the way of the other bank's
+// stage-1/2 launch, under which the two short kernels hide anyway (0.219 against 0.194 ms per step of both banks).
+#include <atomic>
+static std::atomic<int> g_banks_on_device[64];
+
+// k_tail_agc is taken automatically by banks of SDRX_TAILAGC_AUTO_MIN_CU .. SDRX_TAILAGC_AUTO_MAX_CU channels per CU of the device
+// (256 .. 1 024 channels on an MI355X): measured against k_tail_s + k_agc, ms per block, bench.py's channel lists: 256 channels
+// 0.0753 / 0.0764, 384: 0.0840 / 0.0869, 512: 0.1003 / 0.1052, 768: 0.1275 / 0.1307, BASELINE configs[2]'s 1 024: 0.1276 / 0.1329; below
+// (64: 0.0560 / 0.0536, 128: 0.0611 / 0.0596, 192: 0.0681 / 0.0669) the two kernels' own chains are shorter than its pipeline's fill,
+// above (1 280: 0.184 / 0.165, 2 048: 0.256 / 0.237) its workgroups no longer fit the chip at once (profiles/r05_tail_agc.txt)
+#ifndef SDRX_TAILAGC_AUTO_MIN_CU
+#define SDRX_TAILAGC_AUTO_MIN_CU 1
+#endif
+#ifndef SDRX_TAILAGC_AUTO_MAX_CU
+#define SDRX_TAILAGC_AUTO_MAX_CU 4
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -488,9 +509,14 @@ struct sdrxgpu_bank {
     int hist_cur = 0;
     // tail stages + AGC/demod as ONE kernel (k_tail_agc, kernels_tailagc.hpp): banks on the separate tail whose tail is a latency chain
     bool tail_agc = false;
+    bool tail_agc_required = false;           //   tuning.tail_agc = 2: also when other banks share the device
+    bool counted = false;                     // this bank is in g_banks_on_device
     int ta_cpg = 4;                           //   channels per workgroup of that kernel
+    int ta_nt = 2;                            //   its producer waves per workgroup
     TailAgcKernel ta_kernel = nullptr;
     size_t ta_lds = 0;                        //   LDS of its fixed part
+    uint32_t *d_gtab = nullptr;               //   where group g of a call's stage-2 outputs lies in a channel's scratch row
+    int gtab_len = 0;
     int tile_b = 64;                          // final outputs per k_tail workgroup (64: 8 workgroups per CU)
     bool tail_generic = false;                // tuning.tail_generic: run-time-tap k_tail even for the compiled-in chains
     size_t tail_lds = 0;
@@ -622,6 +648,7 @@ static int free_bank(sdrxgpu_bank *b)
         if (p && hipFree(p) != hipSuccess) n_bad++;
     };
     if (g_creating == b) g_creating = nullptr;
+    if (b->counted) g_banks_on_device[b->device].fetch_sub(1);
     // every stream of the bank first (a pipelined bank's second chain is not ordered behind the bank's stream any more)
     if (b->stream2) (void)hipStreamSynchronize(b->stream2);
     if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
@@ -663,6 +690,7 @@ static int free_bank(sdrxgpu_bank *b)
     fr(b->d_hist3c[0]);
     fr(b->d_hist3c[1]);
     fr(b->d_group_conj);
+    fr(b->d_gtab);
     fr(b->d_keep);
     fr(b->d_audio_keep);
     fr(b->d_state);
@@ -1214,32 +1242,45 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
     }
 
     // Tail stages + AGC/demod as ONE kernel (k_tail_agc, kernels_tailagc.hpp; bit-identical to k_tail_s + k_agc): for banks on the
-    // separate tail with one of the compiled-in tail chains.  A workgroup is `cpg` channels with two producer waves, so the
-    // launch has n_ch / cpg workgroups of four waves.  Never automatic: the producers do not keep up with the AGC chain they
-    // feed, the kernel is slower than the two it replaces; tuning.tail_agc = 2 asks for it.
+    // separate tail with one of the compiled-in tail chains.  A workgroup is 1, 2 or 4 channels with two producer waves each and
+    // the two AGC waves.  Automatic where it is the faster of the two (mid-size banks: the macro above); tuning.tail_agc overrides.
     {
         const int mA = cfg->n_stages == 4 ? (int)b->m[2] : 0, tA = cfg->n_stages == 4 ? (int)b->ntaps[2] : 0;
         const int mB = (int)b->m[cfg->n_stages - 1], tB = (int)b->ntaps[cfg->n_stages - 1];
         bool any_fm_ = false;                      // (a bank of AM channels only keeps the AM-only kernel, as below for k_agc)
         for (uint32_t c = 0; cfg->modulation && c < b->n_ch; c++) any_fm_ = any_fm_ || cfg->modulation[c] == SDRXGPU_MOD_FM;
-        const bool compiled = find_tail_agc(mA, tA, mB, tB, cfg->sql_level != nullptr, any_fm_, &b->ta_kernel, &b->ta_lds);
-        // (the index table: one entry per group of Y2B stage-2 outputs of the longest call)
-        const size_t lds_max = b->ta_lds + ((size_t)max_y2 / k12->Y2B + 2) * sizeof(uint32_t);
-        const bool can = compiled && !b->fused && !b->mfma3 && !b->tail_generic && lds_max <= 160 * 1024;
-        if (tune.tail_agc > 2 || tune.tail_agc_cpg > (uint32_t)kTaMaxCpg) {
+        if (tune.tail_agc > 2) {
             free_bank(b);
             return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.tail_agc %u (0 = auto, 1 = never, 2 = require) / tail_agc_cpg %u (0 = auto, 1..%d)",
                         tune.tail_agc, tune.tail_agc_cpg, kTaMaxCpg);
         }
+        const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        // 1, 2 or 4 channels per workgroup (two producer waves each + the two AGC waves): as few as still give every CU at most one
+        // workgroup; tuning.tail_agc_cpg sets it instead.
+        // (2: at 768 channels 4 were 2.5 % faster, at 1 024 the same -- but a workgroup of 4 channels holds 150 KB of LDS, a CU then has
+        // room for nothing else, and two banks on one GPU (BASELINE configs[4]) lost 15 % of their overlap: 0.219 against 0.190 ms)
+        b->ta_nt = (int)b->n_ch <= n_cu / 2 ? 1 : 2;
+        if (tune.tail_agc_cpg) {
+            if (tune.tail_agc_cpg != 1 && tune.tail_agc_cpg != 2 && tune.tail_agc_cpg != 4) {
+                free_bank(b);
+                return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.tail_agc_cpg %u (0 = auto, 1, 2 or 4 channels per workgroup)", tune.tail_agc_cpg);
+            }
+            b->ta_nt = (int)tune.tail_agc_cpg;
+        }
+        b->ta_cpg = b->ta_nt;
+        const bool compiled = find_tail_agc(b->ta_nt, mA, tA, mB, tB, cfg->sql_level != nullptr, any_fm_, &b->ta_kernel, &b->ta_lds);
+        // (the index table: one entry per group of Y2B stage-2 outputs of the longest call, in whole 16-byte pieces)
+        b->gtab_len = (((int)max_y2 / k12->Y2B + 2) + 3) / 4 * 4;
+        const size_t lds_max = b->ta_lds + (size_t)b->gtab_len * sizeof(uint32_t);
+        const bool can = compiled && !b->fused && !b->mfma3 && !b->tail_generic && lds_max <= 160 * 1024;
         if (tune.tail_agc == 2 && !can) {
             free_bank(b);
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.tail_agc = 2, but k_tail_agc is built for the separate tail of the reference's "
-                        "chains (not with stage 3 fused into the stage-1/2 kernel, not with tail_generic)");
+                        "chains (not with stage 3 fused into the stage-1/2 kernel, not with tail_generic; %zu B of LDS)", lds_max);
         }
-        const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        b->tail_agc = can && (tune.tail_agc == 2 || (tune.tail_agc == 0 && (int)b->n_ch <= SDRX_TAILAGC_AUTO_MAX));
-        // channels per workgroup: as few as still fill the chip once (2 workgroups per CU), at most 4 (two per producer wave)
-        b->ta_cpg = tune.tail_agc_cpg ? (int)tune.tail_agc_cpg : std::max(1, std::min(4, ((int)b->n_ch + 2 * n_cu - 1) / (2 * n_cu)));
+        b->tail_agc_required = tune.tail_agc == 2;
+        b->tail_agc = can && (tune.tail_agc == 2 || (tune.tail_agc == 0 && (int)b->n_ch >= SDRX_TAILAGC_AUTO_MIN_CU * n_cu &&
+                                                     (int)b->n_ch <= SDRX_TAILAGC_AUTO_MAX_CU * n_cu));
         if (b->tail_agc) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(b->ta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
             if (e != hipSuccess) {
@@ -1608,6 +1649,28 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
             return fail(SDRXGPU_ERR_HIP, "pipelined-mode stream/event creation failed: %s", hipGetErrorString(e));
         }
     }
+    if (b->tail_agc) {
+        // k_tail_agc's index table: where group gi of a call's stage-2 outputs (time index gi * Y2B) lies in a channel's scratch row --
+        // y2_group_index / y2_storage_index of kernels.hpp with exact integer divisions (the bank's geometry, the same for every call)
+        std::vector<uint32_t> tab((size_t)b->gtab_len);
+        const int y2b = k12->Y2B, seg_len = b->bps * y2b, ph_len = b->nb * y2b, spw = kWave / b->CPW;
+        for (int gi = 0; gi < b->gtab_len; gi++) {
+            const int j = gi * y2b;
+            const int seg = j / seg_len, r = j - seg * seg_len, pp = r / ph_len, r2 = r - pp * ph_len, body = r2 / y2b;
+            const int g = seg / spw, sl = seg % spw, wt = g * b->P + pp;
+            tab[gi] = b->mfma ? (uint32_t)(((wt * 2 * b->nb + 2 * body) * spw + sl) * 2)          // half-body rows (TailArgs.half_split)
+                              : (uint32_t)(((wt * b->nb + body) * spw + sl) * y2b);
+        }
+        if ((rc = dev_alloc(b, (void **)&b->d_gtab, tab.size() * sizeof(uint32_t)))) {
+            free_bank(b);
+            return rc;
+        }
+        hipError_t e = upload(b, b->d_gtab, tab.data(), tab.size() * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            free_bank(b);
+            return fail(SDRXGPU_ERR_HIP, "index table upload failed: %s", hipGetErrorString(e));
+        }
+    }
     rc = init_state(b);
     if (rc) {
         free_bank(b);
@@ -1620,6 +1683,10 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
 #elif SDRX_LAB_CREATE_SYNC == 2
     HIPCHK(hipStreamSynchronize(nullptr));
 #endif
+    if (b->device >= 0 && b->device < 64) {
+        g_banks_on_device[b->device].fetch_add(1);
+        b->counted = true;
+    }
     *out = b;
     return SDRXGPU_OK;
 }
@@ -2273,7 +2340,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         else
             return fail(SDRXGPU_ERR_HIP, "internal: no k_tail4 for this chain");
         HIPCHK(hipGetLastError());
-    } else if (b->tail_agc && t.n_b > 0) {
+    } else if (b->tail_agc && t.n_b > 0 && (b->tail_agc_required || g_banks_on_device[b->device & 63].load() <= 1)) {
         // tail stages + AGC/demod in one kernel (k_tail_agc): the tile hand-over through LDS replaces the launch boundary
         t.hist_in = b->d_hist[b->hist_cur];
         t.hist_out = b->d_hist[b->hist_cur ^ 1];
@@ -2284,7 +2351,10 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         f.n_groups = (t.n_y2_new + t.y2b - 1) >> t.y2b_shift;
         const unsigned blocks = (n_part + (unsigned)f.cpg - 1) / (unsigned)f.cpg + (f.g.roll_cnt > 0 ? 1u : 0u);
         ProfScope ps(b, SDRXGPU_K_TAIL);
-        hipLaunchKernelGGL(b->ta_kernel, dim3(blocks), dim3((kTaNT + 2) * kWave), b->ta_lds + (size_t)f.n_groups * sizeof(uint32_t), b->stream, f);
+        f.gtab = b->d_gtab;
+        if (f.n_groups > b->gtab_len) return fail(SDRXGPU_ERR_HIP, "internal: %d groups, index table of %d", f.n_groups, b->gtab_len);
+        hipLaunchKernelGGL(b->ta_kernel, dim3(blocks), dim3((2 * b->ta_nt + 2) * kWave), b->ta_lds + (size_t)((f.n_groups + 3) / 4 * 4) * sizeof(uint32_t),
+                           b->stream, f);
         HIPCHK(hipGetLastError());
         agc_done = true;
         if (last) b->hist_cur ^= 1;

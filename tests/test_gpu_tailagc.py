@@ -50,7 +50,7 @@ def _same(a, b):
     assert a[4].samples_out == b[4].samples_out
 
 
-@pytest.mark.parametrize("n_ch,cpg", [(1024, 0), (64, 0), (64, 4), (333, 3), (37, 16), (5, 2), (1, 1), (2000, 0)])
+@pytest.mark.parametrize("n_ch,cpg", [(1024, 0), (64, 0), (64, 4), (333, 2), (37, 4), (5, 2), (1, 1), (2000, 0), (300, 0)])
 def test_same_bits_as_the_two_kernels_whole_blocks(oracle, n_ch, cpg):
     ch = chains.chain("10")
     offs = chains.offsets_for_config("c3") if n_ch == 1024 else chains.offsets_cycled(n_ch, ch.N)
@@ -156,8 +156,10 @@ def test_refusals_and_automatic_choice():
         sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"tail_agc": 3})
     assert e.value.code == -1
     with pytest.raises(sb.SdrxGpuError) as e:
-        sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"tail_agc_cpg": 17})
+        sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"tail_agc_cpg": 3})
     assert e.value.code == -1
-    small = sb.ChannelBank(tabs, ch.stage_tuples())
-    assert small.info().tail_agc == 0               # never automatic: slower than k_tail_s + k_agc at every size
-    small.close()
+    # automatic where it is the faster of the two: mid-size banks
+    for n, want in ((64, 0), (512, 2), (1024, 2), (2048, 0)):
+        bk = sb.ChannelBank(sb.translators_for(ch, chains.offsets_cycled(n, ch.N)), ch.stage_tuples())
+        assert bk.info().tail_agc == want, (n, bk.info().tail_agc)
+        bk.close()
