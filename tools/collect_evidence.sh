@@ -8,14 +8,19 @@ set -u
 cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=8      # (what bench.py sets for itself; under rocprofv3 the runtime starts before the program does)
 E=gpurun_out/ev; rm -rf $E; mkdir -p $E
-rm -f gpurun_out/parity_margins.jsonl gpurun_out/r04_parity_pairs.jsonl
+rm -f gpurun_out/parity_margins.jsonl gpurun_out/r05_parity_pairs.jsonl
 step() { tools/run_gpu_step.sh "$@" || exit 1; }
 step 900 $E/gpu_tests.log python -m pytest tests -m gpu -q
-cp gpurun_out/parity_margins.jsonl gpurun_out/r04_parity_pairs.jsonl $E/ 2>/dev/null
+cp gpurun_out/parity_margins.jsonl gpurun_out/r05_parity_pairs.jsonl $E/ 2>/dev/null
 step 400 $E/bench.log python bench.py
 step 200 $E/bench_vector.log python bench.py --matrix 1 --no-cpu-baseline --no-extra-configs
 step 200 $E/bench_vector_separate_tail.log python bench.py --matrix 1 --fused 1 --no-cpu-baseline --no-extra-configs
-step 200 $E/bench_rccl_1rank.log python bench.py --force-dist --no-cpu-baseline --no-extra-configs
+step 200 $E/bench_rccl_1rank.log python bench.py --force-dist --fanout rccl --no-cpu-baseline --no-extra-configs
+step 200 $E/bench_host_1rank.log python bench.py --force-dist --fanout host --no-cpu-baseline --no-extra-configs
+step 200 $E/bench_c4_host_1rank.log python bench.py --config c4 --force-dist --fanout host --steps 300 --no-cpu-baseline
+step 200 $E/bench_c4_rccl_1rank.log python bench.py --config c4 --force-dist --fanout rccl --steps 300 --no-cpu-baseline
+step 300 $E/bench_c4_2ranks_1gpu.log python bench.py --config c4 --gpus 2 --fanout host --ranks-on-one-gpu --steps 300 --no-cpu-baseline
+step 300 $E/bench_multibank_2x5000.log python bench.py --multibank 2 --channels 5000 --steps 300
 step 200 $E/bench_fused3.log python bench.py --matrix 3 --no-cpu-baseline --no-extra-configs
 step 200 $E/bench_c4.log python bench.py --config c4 --steps 300 --no-cpu-baseline
 step 200 $E/bench_c5.log python bench.py --config c5 --steps 300 --no-cpu-baseline

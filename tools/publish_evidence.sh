@@ -8,6 +8,11 @@ j $E/bench.log $P/${T}_bench.json
 j $E/bench_vector.log $P/${T}_bench_vector_kernels.json
 j $E/bench_vector_separate_tail.log $P/${T}_bench_vector_kernels_separate_tail.json
 j $E/bench_rccl_1rank.log $P/${T}_bench_rccl_1rank.json
+j $E/bench_host_1rank.log $P/${T}_bench_host_fanout_1rank.json
+j $E/bench_c4_host_1rank.log $P/${T}_bench_config_c4_host_fanout_1rank.json
+j $E/bench_c4_rccl_1rank.log $P/${T}_bench_config_c4_rccl_1rank.json
+j $E/bench_c4_2ranks_1gpu.log $P/${T}_bench_config_c4_2ranks_on_one_gpu.json
+j $E/bench_multibank_2x5000.log $P/${T}_bench_multibank_2x5000.json
 j $E/bench_fused3.log $P/${T}_bench_fused_stage3.json
 j $E/bench_c4.log $P/${T}_bench_config_c4.json
 j $E/bench_c5.log $P/${T}_bench_config_c5.json
@@ -15,7 +20,7 @@ j $E/bench_under_rocprof_trace_fused3.log $P/${T}_bench_under_rocprof_fused_stag
 cp "$(ls -t $E/trace_fused3/runc/*_kernel_stats.csv | head -1)" $P/${T}_kernel_stats_fused_stage3.csv
 cp $E/pmc_fused3/summary.txt $P/${T}_fused_stage3_pmc_summary.txt;  cp $E/pmc_fused3/traffic.json $P/${T}_fused_stage3_traffic.json
 cp $E/trace_outliers.txt $P/${T}_trace_outliers.txt
-cp $E/r04_parity_pairs.jsonl $P/${T}_parity_pairs.jsonl
+cp $E/r05_parity_pairs.jsonl $P/${T}_parity_pairs.jsonl
 j $E/bench_under_rocprof_trace.log $P/${T}_bench_under_rocprof.json
 j $E/bench_under_rocprof_trace_vector.log $P/${T}_bench_under_rocprof_vector_kernels.json
 cp "$(ls -t $E/trace/runc/*_kernel_stats.csv | head -1)" $P/${T}_kernel_stats.csv
