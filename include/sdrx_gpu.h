@@ -362,8 +362,11 @@ int sdrxgpu_multibank_get_info(sdrxgpu_multibank *mb, sdrxgpu_multibank_info *in
 /* Shard `index` (0 .. n_shards-1): its bank (owned by the multibank; for the getters -- info, gains, squelch, profile --
  * not for process calls), its device and its channel range.  Any pointer may be NULL. */
 int sdrxgpu_multibank_shard(sdrxgpu_multibank *mb, uint32_t index, sdrxgpu_bank **bank, int32_t *device, uint32_t *ch_lo, uint32_t *ch_hi);
-/* sdrxgpu_bank_get_agc_state over all shards, in channel order. */
+/* sdrxgpu_bank_get_agc_state / _get_gains / _get_squelch over all shards, in channel order (what sdrx prints per channel,
+ * sdrx.cpp:593-634). */
 int sdrxgpu_multibank_get_agc_state(sdrxgpu_multibank *mb, float *agc_gain, float *agc_power, float *lf_gain, float *lf_power);
+int sdrxgpu_multibank_get_gains(sdrxgpu_multibank *mb, float *agc_gain, float *lf_agc_gain);
+int sdrxgpu_multibank_get_squelch(sdrxgpu_multibank *mb, float *snr_db, unsigned char *state);
 
 /* Squelch SNR (dB) and state (0 closed / 1 open) per channel after the last chunk (what sdrx prints,
  * sdrx.cpp:593-634); either may be NULL. */

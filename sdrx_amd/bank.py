@@ -167,6 +167,8 @@ def load_library():
     L.sdrxgpu_multibank_get_info.argtypes = [vp, C.POINTER(MultiBankInfo)]
     L.sdrxgpu_multibank_shard.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_int32), u32p, u32p]
     L.sdrxgpu_multibank_get_agc_state.argtypes = [vp, vp, vp, vp, vp]
+    L.sdrxgpu_multibank_get_gains.argtypes = [vp, vp, vp]
+    L.sdrxgpu_multibank_get_squelch.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -181,7 +183,7 @@ EXPORTED_SYMBOLS = [
     "sdrxgpu_version",
     "sdrxgpu_shard_range", "sdrxgpu_multibank_create", "sdrxgpu_multibank_destroy", "sdrxgpu_multibank_reset", "sdrxgpu_multibank_process",
     "sdrxgpu_multibank_process_pinned", "sdrxgpu_multibank_synchronize", "sdrxgpu_multibank_get_info", "sdrxgpu_multibank_shard",
-    "sdrxgpu_multibank_get_agc_state",
+    "sdrxgpu_multibank_get_agc_state", "sdrxgpu_multibank_get_gains", "sdrxgpu_multibank_get_squelch",
 ]
 
 
@@ -567,5 +569,17 @@ class MultiChannelBank(ChannelBank):
     def _no(self, *a, **k):
         raise SdrxGpuError(-5, "MultiChannelBank", "not available across devices (use the shards' banks)")
 
-    gains = squelch_state = mix = process_device = flush = ingest_buffer = ingest_buffer_after = _no
+    def gains(self):
+        a = np.empty(self.n_channels, dtype=np.float32)
+        b = np.empty(self.n_channels, dtype=np.float32)
+        _check(self._L.sdrxgpu_multibank_get_gains(self._h, a.ctypes.data, b.ctypes.data), "sdrxgpu_multibank_get_gains")
+        return a, b
+
+    def squelch_state(self):
+        snr = np.empty(self.n_channels, dtype=np.float32)
+        st = np.empty(self.n_channels, dtype=np.uint8)
+        _check(self._L.sdrxgpu_multibank_get_squelch(self._h, snr.ctypes.data, st.ctypes.data), "sdrxgpu_multibank_get_squelch")
+        return snr, st
+
+    mix = process_device = flush = ingest_buffer = ingest_buffer_after = _no
     profile_enable = profile_reset = profile_read = _no

@@ -359,3 +359,28 @@ extern "C" int sdrxgpu_multibank_get_agc_state(sdrxgpu_multibank *mb, float *agc
     (void)hipSetDevice(prev_dev);
     return rc;
 }
+
+// what sdrx prints per channel (-v: AGC gains, SNR and squelch state, sdrx.cpp:593-634), over all shards in channel order
+extern "C" int sdrxgpu_multibank_get_gains(sdrxgpu_multibank *mb, float *agc_gain, float *lf_agc_gain)
+{
+    if (!mb) return fail(SDRXGPU_ERR_INVALID_ARG, "multibank_get_gains: null multibank");
+    int prev_dev = 0;
+    (void)hipGetDevice(&prev_dev);
+    int rc = SDRXGPU_OK;
+    for (const auto &s : mb->shards)
+        if ((rc = sdrxgpu_bank_get_gains(s.bank, agc_gain ? agc_gain + s.ch_lo : nullptr, lf_agc_gain ? lf_agc_gain + s.ch_lo : nullptr))) break;
+    (void)hipSetDevice(prev_dev);
+    return rc;
+}
+
+extern "C" int sdrxgpu_multibank_get_squelch(sdrxgpu_multibank *mb, float *snr_db, unsigned char *state)
+{
+    if (!mb) return fail(SDRXGPU_ERR_INVALID_ARG, "multibank_get_squelch: null multibank");
+    int prev_dev = 0;
+    (void)hipGetDevice(&prev_dev);
+    int rc = SDRXGPU_OK;
+    for (const auto &s : mb->shards)
+        if ((rc = sdrxgpu_bank_get_squelch(s.bank, snr_db ? snr_db + s.ch_lo : nullptr, state ? state + s.ch_lo : nullptr))) break;
+    (void)hipSetDevice(prev_dev);
+    return rc;
+}

@@ -145,9 +145,14 @@ def test_squelch_and_modulation_arrays_are_cut_with_the_channels():
     kw = dict(squelch=(level,) + tuple(sq_tabs), modulation=mod)
     one = sb.ChannelBank(tabs, ch.stage_tuples(), **kw)
     want = [one.process(x) for x in blocks]
+    w_sq, w_gains = one.squelch_state(), one.gains()
     one.close()
     mb = sb.MultiChannelBank(tabs, ch.stage_tuples(), devices=(0, 0, 0), **kw)
     for k, x in enumerate(blocks):
         iq, au = mb.process(x)
         assert np.array_equal(_bits(iq), _bits(want[k][0])) and np.array_equal(_bits(au), _bits(want[k][1]))
+    # what sdrx prints per channel (sdrx.cpp:593-634), over all shards in channel order
+    sq, gains = mb.squelch_state(), mb.gains()
+    assert np.array_equal(_bits(sq[0]), _bits(w_sq[0])) and np.array_equal(sq[1], w_sq[1]) and len(set(sq[1].tolist())) == 2
+    assert np.array_equal(_bits(gains[0]), _bits(w_gains[0])) and np.array_equal(_bits(gains[1]), _bits(w_gains[1]))
     mb.close()
