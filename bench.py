@@ -237,6 +237,7 @@ def selftest_launch(args):
     from sdrx_amd import dist as sdist
     from sdrx_amd import synth
     rank, _, world = sdist.env_rank_world()
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo")
     ch = chains.chain(args.rate)
     plan = sdist.plan(args.config, rank, world, ch.N, args.channels)
@@ -656,6 +657,8 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "gloo":
+            # one node by contract: the loopback interface always exists, the container's hostname may not resolve
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -46,8 +46,8 @@ def test_host_entry_in_two_halves_equals_device_entry(n_ch, fused, matrix):
     offs = chains.offsets_cycled(n_ch, ch.N)
     tabs = sb.translators_for(ch, offs)
     blocks = _blocks(ch, 3, car=[tabs[7]])
-    # (matrix_pipe 2: k_stage12m + k_tail_s where a bank of this size takes the matrix pipe -- this test ends with a bit-for-bit
-    # comparison of two cuts of the stream, which the default of such a bank, k_stage123m, does not promise: tests/test_gpu_fused3.py)
+    # (the kernel path is pinned per case: the test ends with a bit-for-bit comparison of two cuts of the stream, which holds on every
+    # path but the opt-in fused one, tests/test_gpu_fused3.py)
     # matrix: 2 = k_stage12m + k_tail_s, 1 = the vector kernels with the separate tail, 0 with fused_tail required = k_stage12p + k_tail4
     kw = dict(block_hint=0xFFFFFFFF, tuning={"fused_tail": fused, "matrix_pipe": matrix})
     dev = sb.ChannelBank(tabs, ch.stage_tuples(), **kw)

@@ -142,7 +142,12 @@ def test_automatic_choice_goes_with_the_partners_found_not_with_the_channel_coun
         bank = sb.ChannelBank(sb.translators_for(ch, offs), ch.stage_tuples())
         want[name] = int(bank.info().matrix_pipe)
         bank.close()
-    assert want == {"paired_2400": 1, "one_sided_2400": 0, "config_3_1024": 1, "one_sided_1024": 0, "paired_900": 0, "one_sided_6000": 0}
+    # (what does NOT depend on the device: no partners -> never the matrix pipe; under 1 024 channels -> never.  The paired banks'
+    # answer comes from the launch-count model, which counts the device's CUs: on a 256-CU MI355X it says yes for both)
+    assert (want["one_sided_2400"], want["one_sided_1024"], want["paired_900"], want["one_sided_6000"]) == (0, 0, 0, 0)
+    import torch
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert (want["paired_2400"], want["config_3_1024"]) == (1, 1)
 
 
 @pytest.mark.parametrize("n_ch", [3584, 10000])
@@ -153,7 +158,7 @@ def test_large_bank_host_parts_and_oracle(oracle, n_ch):
     tabs = sb.translators_for(ch, offs)
     L = ch.block_len
     blocks = [synth.synth_iq(9, b * L, L, 0.25, [tabs[650]], [0.2], ch.N, 10000) for b in range(2)]
-    bank = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": REQ})     # (the default of such a bank is k_stage123m: test_gpu_fused3.py)
+    bank = sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"matrix_pipe": REQ})     # (what such a bank takes by itself; pinned: the test is about this kernel)
     info = bank.info()
     assert info.matrix_pipe == 1
     outs = [bank.process(x) for x in blocks]                # host entry: channel parts, D2H beside the kernels
