@@ -1699,9 +1699,6 @@ __global__ __launch_bounds__(4 * kWave) void k_agc(const AgcArgs a)
         }
     } else if (wave == 0) {
         // ---- IF AGC ----
-#ifdef SDRX_LAB_AGC_PRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
         const float4 s4 = a.state[ch];
         float g = s4.x, pw = s4.y;
         __syncthreads();
@@ -1743,9 +1740,6 @@ __global__ __launch_bounds__(4 * kWave) void k_agc(const AgcArgs a)
         if (ok) reinterpret_cast<float2 *>(a.state + ch)[0] = make_float2(g, pw);
     } else if (wave == 1) {
         // ---- envelope / FM phase step -> LF AGC -> squelch gating, one tile behind wave 0 ----
-#ifdef SDRX_LAB_AGC_PRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
         const float4 s4 = a.state[ch];
         float gl = s4.z, pl = s4.w;
         bool is_fm = false;
