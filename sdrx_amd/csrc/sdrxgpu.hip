@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 #include "kernels_mfma.hpp"
 #include "kernels_mfma3.hpp"
+#include "kernels_mfma6.hpp"
 #include "kernels_tailagc.hpp"
 
 #include <algorithm>
@@ -297,10 +298,19 @@ struct K12mLaunch {
     K12Launch L;
     PairArgs pa;
     int GS, GT;
+    int kind;            // 0: k_stage12m (10 MS/s chain, (5, 17)(5, 19)); 1: k_stage12m6 (6 MS/s chain, (15, 53)(5, 21))
 };
 
-static bool k12m_geometry_compiled(int GS, int GT) { return (GS == 2 && GT == 2) || (GS == 4 && GT == 2) || (GS == 2 && GT == 4); }
-static size_t k12m_lds_bytes(int GS, int GT) { return 2 * (size_t)(16 * GS + 16 * GT) * 528; }
+static bool k12m_geometry_compiled(int kind, int GS, int GT)
+{
+    if (kind == 1) return GS == 2 && GT == 2;
+    return (GS == 2 && GT == 2) || (GS == 4 && GT == 2) || (GS == 2 && GT == 4);
+}
+static size_t k12m_lds_bytes(int kind, int GS, int GT)
+{
+    if (kind == 1) return 2 * (size_t)TileGeomM6<2, 2>::buf_bytes;
+    return 2 * (size_t)(16 * GS + 16 * GT) * 528;
+}
 
 template <int GS, int GT>
 static hipError_t launch_k12m_one(const K12mLaunch &M, const Stage12mTaps &taps, hipStream_t s)
@@ -314,6 +324,15 @@ static hipError_t launch_k12m_one(const K12mLaunch &M, const Stage12mTaps &taps,
 
 static hipError_t launch_k12m(const K12mLaunch &M, hipStream_t s)
 {
+    if (M.kind == 1) {
+        Stage12m6Taps t6{};
+        for (int i = 0; i < 53; i++) t6.h1[i] = M.L.h1[i < 27 ? i : 52 - i];   // (the reference reads h[0 .. half] only, msd.hpp:309-331)
+        for (int i = 0; i < 11; i++) t6.h2[i] = M.L.h2[i];
+        using TG = TileGeomM6<2, 2>;
+        static_assert(2 * TG::buf_bytes <= 160 * 1024, "two tile buffers must fit the LDS");
+        hipLaunchKernelGGL((k_stage12m6<2, 2>), dim3(M.L.grid), dim3(64 * TG::waves), 2 * TG::buf_bytes, s, M.L.x, M.L.tables, M.L.y2, M.L.args, M.pa, t6);
+        return hipGetLastError();
+    }
     Stage12mTaps taps{};
     for (int i = 0; i < 17; i++) taps.h1[i] = M.L.h1[i < 9 ? i : 16 - i];     // (the reference reads h[0 .. half] only, msd.hpp:309-331)
     for (int i = 0; i < 10; i++) taps.h2[i] = M.L.h2[i];
@@ -323,9 +342,12 @@ static hipError_t launch_k12m(const K12mLaunch &M, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
-static hipError_t k12m_set_attributes(int GS, int GT)
+static hipError_t k12m_set_attributes(int kind, int GS, int GT)
 {
-    const int n = (int)k12m_lds_bytes(GS, GT);
+    if (kind == 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage12m6<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)k12m_lds_bytes(1, 2, 2));
+    const int n = (int)k12m_lds_bytes(0, GS, GT);
     const void *f = nullptr;
     if (GS == 2 && GT == 2) f = reinterpret_cast<const void *>(&k_stage12m<2, 2>);
     if (GS == 4 && GT == 2) f = reinterpret_cast<const void *>(&k_stage12m<4, 2>);
@@ -447,6 +469,11 @@ static long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) 
 #include <atomic>
 static std::atomic<int> g_banks_on_device[64];
 
+// smallest bank (channels) of the 6 MS/s chain that takes k_stage12m6 by itself (lab builds: -DSDRX_M6_AUTO_MIN=...)
+#ifndef SDRX_M6_AUTO_MIN
+#define SDRX_M6_AUTO_MIN 1000000000
+#endif
+
 // k_tail_agc is taken automatically by banks of SDRX_TAILAGC_AUTO_MIN_CU .. SDRX_TAILAGC_AUTO_MAX_CU channels per CU of the device
 // (256 .. 1 024 channels on an MI355X): measured against k_tail_s + k_agc, ms per block, bench.py's channel lists: 256 channels
 // 0.0753 / 0.0764, 384: 0.0840 / 0.0869, 512: 0.1003 / 0.1052, 768: 0.1275 / 0.1307, BASELINE configs[2]'s 1 024: 0.1276 / 0.1329; below
@@ -566,6 +593,7 @@ struct sdrxgpu_bank {
     // mixer + stage 1 on the f32 matrix pipe (k_stage12m): slot list {channel, its conjugate partner or -1; {-1,-1}: empty},
     // ordered by host part, every part's share padded to whole workgroup sets of 16 * mGS slots
     bool mfma = false;
+    int mfma_kind = 0;               // 0: k_stage12m (10 MS/s chain); 1: k_stage12m6 (6 MS/s chain)
     int mGS = 2, mGT = 2;
     // ... and stages 2-3 behind it in the same kernel, no stage-2 scratch (k_stage123m + k_tail_c, kernels_mfma3.hpp): the
     // coefficient table of the combined stage-2/3 filter, the stage-3 scratch [channel][segment group][entry][segment] and, per
@@ -899,10 +927,12 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = 3, but k_stage123m is built for the whole 10 MS/s chain "
                         "((5,17)(5,19)(5,21)(5,67), N = 1200), not pipelined, whole segments per lane");
         }
-        if (tune0.matrix_pipe == 2 && !can) {
+        // ... and the 6 MS/s chain's first two stages, (15, 53)(5, 21): k_stage12m6 (kernels_mfma6.hpp)
+        const bool can6 = k12->M1 == 15 && k12->T1 == 53 && k12->M2 == 5 && k12->T2 == 21 && k12->Y2B == 2 && N > 0 && (N % 2) == 0 && !b->pipelined;
+        if (tune0.matrix_pipe == 2 && !can && !can6) {
             free_bank(b);
-            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = 2, but k_stage12m is built for the 10 MS/s chain "
-                        "(stages (5,17)(5,19)) with translator tables of even length");
+            return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.matrix_pipe = 2, but the matrix-pipe kernels are built for the 10 MS/s chain "
+                        "(stages (5,17)(5,19): k_stage12m) and the 6 MS/s chain ((15,53)(5,21): k_stage12m6), with translator tables of even length");
         }
         // (automatic only where nothing else about the stage-1/2 kernel is asked for: a required fused tail, required pair lanes
         // or a forced geometry mean the vector kernels)
@@ -913,16 +943,19 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         }
         // automatic: from 1 024 channels (where the vector path is k_stage12p), if enough of them have their conjugate partner in
         // the bank (decided below, once the partners are known)
-        b->mfma = can && (tune0.matrix_pipe >= 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 1024));
+        b->mfma = (can && (tune0.matrix_pipe >= 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 1024))) ||
+                  (can6 && (tune0.matrix_pipe == 2 || (tune0.matrix_pipe == 0 && !others && (int)b->n_ch >= SDRX_M6_AUTO_MIN)));
+        b->mfma_kind = (b->mfma && can6) ? 1 : 0;
         // (never automatic: 11 % faster per block, but 2 to 3 x the reference's own build-to-build rounding spread on channels next
         // to a strong carrier, where k_stage12m is at 1.1 to 1.4 x: DESIGN.md 4.9 -- a caller's choice, SDRXGPU_FLAG_FUSED_STAGE3)
         b->mfma3 = b->mfma && can3 && (tune0.matrix_pipe == 3 || (tune0.matrix_pipe == 0 && (cfg->flags & SDRXGPU_FLAG_FUSED_STAGE3)));
         if (b->mfma) {
             b->mGS = tune0.m_slot_groups ? (int)tune0.m_slot_groups : 2;
             b->mGT = tune0.m_seg_groups ? (int)tune0.m_seg_groups : 2;
-            if (!k12m_geometry_compiled(b->mGS, b->mGT)) {
+            if (!k12m_geometry_compiled(b->mfma_kind, b->mGS, b->mGT)) {
                 free_bank(b);
-                return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: k_stage12m is not compiled for %d x %d tiles per workgroup", b->mGS, b->mGT);
+                return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: %s is not compiled for %d x %d tiles per workgroup",
+                            b->mfma_kind ? "k_stage12m6" : "k_stage12m", b->mGS, b->mGT);
             }
             b->HIST = ((b->WU * b->SB + b->MM + (k12->T1 - k12->M1) + 7) / 8) * 8;
         }
@@ -1001,7 +1034,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         // (0.97; 0.96), 1 152: 0.098 / 0.118 (0.83; 0.94), 1 408: 0.108 / 0.145 (0.75; 0.90), 1 536: 0.148 / 0.139 (1.07; 1.07),
         // 1 792: 0.162 / 0.152 (1.07; 1.16), 896: 0.097 / 0.095 (1.02; 1.33) -- where the prediction is under 0.97 the matrix
         // pipe was ahead at every size measured (profiles/r04_lab_matrix_pipe_choice.txt).  Automatic = predicted ratio under 0.97.
-        if (tune0.matrix_pipe == 0) {
+        if (tune0.matrix_pipe == 0 && b->mfma_kind == 0) {        // (k_stage12m6: by the channel count alone, SDRX_M6_AUTO_MIN)
             const long long max_chunk = cfg->max_in_len ? cfg->max_in_len : 512LL * b->m_total;
             const long long U = (max_chunk / b->MM + 1 + k12->Y2B - 1) / k12->Y2B;
             const long long n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1018,7 +1051,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
                 return best;
             };
             const long long g16 = (U + 16LL * b->bps - 1) / (16LL * b->bps);                        // segment groups of 16
-            const long long places_m = n_cu_ * std::max<long long>(1, (long long)(160 * 1024 / k12m_lds_bytes(b->mGS, b->mGT)));
+            const long long places_m = n_cu_ * std::max<long long>(1, (long long)(160 * 1024 / k12m_lds_bytes(b->mfma_kind, b->mGS, b->mGT)));
             const double cost_m = launch_cost((long long)(m_slots_all.size() / m_set) * ((g16 + b->mGT - 1) / b->mGT), places_m);
             const double cost_v = launch_cost(((long long)b->n_ch + 2 * kPairSlots - 1) / (2 * kPairSlots) * g16, 2 * n_cu_);
             // (15.0 us: the 2 x 2 workgroup's body; other shapes -- a test knob -- in proportion to their waves)
@@ -1183,7 +1216,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
             // workgroups of mGS x mGT tiles, two (256 threads) or one (512) per CU; same count of rounds x bodies as above
             const long long Gs = (U + 16LL * b->bps - 1) / (16LL * b->bps);
             const long long sets = (long long)m_slots_all.size() / m_set;      // (exact: partners found, not channels / 2)
-            const long long slots = (long long)n_cu * std::max<long long>(1, (long long)(160 * 1024 / k12m_lds_bytes(b->mGS, b->mGT)));
+            const long long slots = (long long)n_cu * std::max<long long>(1, (long long)(160 * 1024 / k12m_lds_bytes(b->mfma_kind, b->mGS, b->mGT)));
             double best_cost = -1.0;
             for (int nb = b->bps; nb >= 1; nb--) {
                 if (b->bps % nb) continue;
@@ -1409,7 +1442,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         b->d_slots_mp = b->d_slots_m + slots_all.size();
         hipError_t e = upload(b, b->d_slots_m, slots_all.data(), slots_all.size() * sizeof(int2));
         if (e == hipSuccess) e = upload(b, b->d_slots_mp, slots_parts.data(), slots_parts.size() * sizeof(int2));
-        if (e == hipSuccess) e = k12m_set_attributes(b->mGS, b->mGT);
+        if (e == hipSuccess) e = k12m_set_attributes(b->mfma_kind, b->mGS, b->mGT);
         if (e == hipSuccess && b->mfma3) e = k123m_set_attributes(b->mGS, b->mGT);
         if (e != hipSuccess) {
             free_bank(b);
@@ -1658,7 +1691,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
             const int j = gi * y2b;
             const int seg = j / seg_len, r = j - seg * seg_len, pp = r / ph_len, r2 = r - pp * ph_len, body = r2 / y2b;
             const int g = seg / spw, sl = seg % spw, wt = g * b->P + pp;
-            tab[gi] = b->mfma ? (uint32_t)(((wt * 2 * b->nb + 2 * body) * spw + sl) * 2)          // half-body rows (TailArgs.half_split)
+            tab[gi] = (b->mfma && b->mfma_kind == 0) ? (uint32_t)(((wt * 2 * b->nb + 2 * body) * spw + sl) * 2)   // half-body rows (TailArgs.half_split)
                               : (uint32_t)(((wt * b->nb + body) * spw + sl) * y2b);
         }
         if ((rc = dev_alloc(b, (void **)&b->d_gtab, tab.size() * sizeof(uint32_t)))) {
@@ -1920,7 +1953,8 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
         M.pa.slots = whole ? b->d_slots_m : b->d_slots_mp;
         M.pa.group_conj = nullptr;
         M.pa.n_slots = whole ? b->n_slots_m : b->n_slots_mp;
-        M.pa.lds_bytes = (int)k12m_lds_bytes(b->mGS, b->mGT);
+        M.kind = b->mfma_kind;
+        M.pa.lds_bytes = (int)k12m_lds_bytes(b->mfma_kind, b->mGS, b->mGT);
         if ((uint64_t)(b->n_ch + 1) * (uint64_t)b->y2_stride * sizeof(float2) >= (1ull << 32))
             return fail(SDRXGPU_ERR_HIP, "internal: stage-2 scratch of %u x %d entries exceeds k_stage12m's 32-bit byte offsets", b->n_ch, b->y2_stride);
         HIPCHK(launch_k12m(M, st));
@@ -2214,7 +2248,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         t.rcp_seg_len = 1.0f / (float)t.seg_len;
         t.rcp_ph_len = 1.0f / (float)t.ph_len;
         t.rcp_y2b = 1.0f / (float)t.y2b;
-        t.half_split = b->mfma ? 1 : 0;     // k_stage12m stores by half-bodies of two outputs (kernels_mfma.hpp)
+        t.half_split = (b->mfma && b->mfma_kind == 0) ? 1 : 0;     // k_stage12m stores by half-bodies of two outputs (kernels_mfma.hpp)
         t.n_tiles = std::max(1, (t.n_b + b->tile_b - 1) / b->tile_b);
         if (t.n_b > b->keep_stride) return fail(SDRXGPU_ERR_HIP, "internal: %d outputs > keep_stride %d", t.n_b, b->keep_stride);
         job->valid = true;
