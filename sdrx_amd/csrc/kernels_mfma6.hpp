@@ -157,6 +157,7 @@ void k_stage12m6(const float2 *__restrict__ x_in, const float2 *__restrict__ tab
     for (int j = 0; j < 13; j++) hA[j] = taps.h1[4 * j + hi];
     const float h52 = taps.h1[52];
 
+    struct Ops { float ta[13]; v2f x[13]; v2f x52, t52a, t52b; };        // a phase's operands: A [j], B [j], tap 52
     typedef const volatile __attribute__((address_space(3))) v2f lds_cv2f;
     typedef const volatile __attribute__((address_space(3))) float lds_cvf;
     typedef const __attribute__((address_space(3))) char lds_cc;
@@ -178,35 +179,54 @@ void k_stage12m6(const float2 *__restrict__ x_in, const float2 *__restrict__ tab
     constexpr int WU = 2;
     const int n_chunks = 2 * (WU + a.nb);
     issue_chunk(0, 0);
+    bool stored = false;                                    // the previous chunk ended with the body's four stores
     for (int c = 0; c < n_chunks; c++) {
         // this chunk's rows have landed (own DMAs: vmcnt; everybody's: barrier); the barrier also says every wave is done with
-        // the other buffer, which the next chunk's rows may now overwrite
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // the other buffer, which the next chunk's rows may now overwrite.  The DMAs are older than the previous chunk's stores
+        // (in-order completion): "at most four outstanding" leaves those in flight -- waited for with vmcnt(0), as __syncthreads()
+        // does, every second chunk paid a store round trip (0.456 -> ms per 10 000-channel block).  Hence the raw barrier:
+        // the wave's own LDS reads are done (lgkmcnt), nothing else of this kernel is read by another wave.
+        if (stored) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stored = false;
         if (c + 1 < n_chunks) issue_chunk(c + 1, (c + 1) & 1);
         if (seg_live) {
             const int bo = (c & 1) * G::buf_bytes + (c & 1) * 8;    // (odd chunks: the window starts one entry further in)
             lds_cc *const la = lbase + aoff + bo, *const lb = lbase + boff + bo, *const ld = lbase + doff + bo, *const le = lbase + eoff + bo;
+            // The operands of phase ph + 1 are fetched into the registers the MFMAs of phase ph have just read, and phase ph is
+            // finished on the vector pipe meanwhile (read -> wait -> multiply -> MFMA per K step, the first version, left every one
+            // of the 13 LDS round trips of a phase in the wave's way: 0.50 ms for the 10 000-channel block).
+            auto load_ops = [&](int ph, Ops &o) {
+#pragma unroll
+                for (int j = 0; j < 13; j++) {
+                    o.ta[j] = *(lds_cvf *)(la + (15 * ph + 4 * j) * 8);
+                    o.x[j] = *(lds_cv2f *)(lb + (15 * ph + 4 * j) * 8);
+                }
+                o.x52 = *(lds_cv2f *)(le + (15 * ph + 52) * 8);
+                o.t52a = *(lds_cv2f *)(ld + (15 * ph + 52) * 8);
+                o.t52b = *(lds_cv2f *)(ld + RB + (15 * ph + 52) * 8);
+            };
+            Ops ops;
+            load_ops(0, ops);
 #pragma unroll
             for (int ph = 0; ph < G::PH; ph++) {
                 // ---- tap 52 starts the accumulators: (tr, ti) of a slot times h52 xr resp. h52 xi = the slot's (P, Q) pair ----
-                const v2f x52 = *(lds_cv2f *)(le + (15 * ph + 52) * 8);
-                const v2f t52a = *(lds_cv2f *)(ld + (15 * ph + 52) * 8);
-                const v2f t52b = *(lds_cv2f *)(ld + RB + (15 * ph + 52) * 8);
-                const v2f xh = x52 * v2f{h52, h52};
-                v4f Dr = v4f{t52a.x * xh.x, t52a.y * xh.x, t52b.x * xh.x, t52b.y * xh.x};
-                v4f Di = v4f{t52a.x * xh.y, t52a.y * xh.y, t52b.x * xh.y, t52b.y * xh.y};
+                const v2f xh = ops.x52 * v2f{h52, h52};
+                v4f Dr = v4f{ops.t52a.x * xh.x, ops.t52a.y * xh.x, ops.t52b.x * xh.x, ops.t52b.y * xh.x};
+                v4f Di = v4f{ops.t52a.x * xh.y, ops.t52a.y * xh.y, ops.t52b.x * xh.y, ops.t52b.y * xh.y};
+                v2f xs[13];
+#pragma unroll
+                for (int j = 0; j < 13; j++) xs[j] = ops.x[j] * v2f{hA[j], hA[j]};     // the tap rides on the B operand
                 // ---- 13 K steps, outside-in ----
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int jj = 0; jj < 13; jj++) {
                     const int j = (jj & 1) ? 12 - (jj >> 1) : (jj >> 1);      // 0, 12, 1, 11, 2, 10, 3, 9, 4, 8, 5, 7, 6
-                    const float ta = *(lds_cvf *)(la + (15 * ph + 4 * j) * 8);
-                    const v2f xx = *(lds_cv2f *)(lb + (15 * ph + 4 * j) * 8);
-                    const v2f xs = xx * v2f{hA[j], hA[j]};                     // the tap rides on the B operand
-                    Dr = __builtin_amdgcn_mfma_f32_16x16x4f32(ta, xs.x, Dr, 0, 0, 0);
-                    Di = __builtin_amdgcn_mfma_f32_16x16x4f32(ta, xs.y, Di, 0, 0, 0);
+                    Dr = __builtin_amdgcn_mfma_f32_16x16x4f32(ops.ta[j], xs[j].x, Dr, 0, 0, 0);
+                    Di = __builtin_amdgcn_mfma_f32_16x16x4f32(ops.ta[j], xs[j].y, Di, 0, 0, 0);
                 }
+                if (ph + 1 < G::PH) load_ops(ph + 1, ops);
                 __builtin_amdgcn_s_setprio(0);
                 // ---- channel A = the slot's own table: (Pr - Qi) + j (Pi + Qr); channel B = its conjugate: (Pr + Qi) + j (Pi - Qr) ----
                 v2f Y[4];
@@ -229,6 +249,7 @@ void k_stage12m6(const float2 *__restrict__ x_in, const float2 *__restrict__ tab
                         else acc2[d][i] = __builtin_elementwise_fma(Y[i], h, acc2[d][i]);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // ---- the chunk's output (element 20 came with its last phase) is complete: keep it for the body's store, shift the rest down ----
             const int body = (c >> 1) - WU;
@@ -246,12 +267,13 @@ void k_stage12m6(const float2 *__restrict__ x_in, const float2 *__restrict__ tab
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     *reinterpret_cast<v4f *>(reinterpret_cast<char *>(y2_out) + (size_t)(yrow[i] + at) * 8u) = stage[i];
+                stored = true;
             }
         }
     }
     // (the next item's first rows go to buffer 0: every wave has left it -- the last chunk is odd -- before the barrier above; its own
     // reads of buffer 1 end before the next item's second barrier)
-    if (item + (int)gridDim.x < n_items) __syncthreads();
+    if (item + (int)gridDim.x < n_items) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 

@@ -469,10 +469,13 @@ static long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) 
 #include <atomic>
 static std::atomic<int> g_banks_on_device[64];
 
-// smallest bank (channels) of the 6 MS/s chain that takes k_stage12m6 by itself (lab builds: -DSDRX_M6_AUTO_MIN=...)
-#ifndef SDRX_M6_AUTO_MIN
-#define SDRX_M6_AUTO_MIN 1000000000
-#endif
+// k_stage12m6 (the 6 MS/s chain's matrix pipe) is a caller's choice, tuning.matrix_pipe = 2, never automatic: on the stress fixtures
+// of tests/golden/pairs6 (a carrier of 0.9 of full scale over a floor of 0.05) the carrier's conjugate partner comes out 1.4e-5 from
+// the reference's portable build where the reference's own two builds are 0.42e-5 apart (3.3 x their spread; k_stage12m holds 2.1 x
+// on the 10 MS/s chain's fixtures, and 1e-5 wherever the builds agree to 0.5e-5) -- tests/test_gpu_matrix6.py.  Where it pays, ms
+// per block, vector / matrix (tools/lab/bench_m6_lists.py): 512 channels 0.091 / 0.123, 768: 0.121 / 0.124, 1 024: 0.130 / 0.106,
+// 2 048: 0.219 / 0.158, 4 096: 0.393 / 0.281, 10 000: 0.929 / 0.575; without partners 2 048: 0.217 / 0.201, 10 000: 0.924 / 0.952;
+// half of the channels paired, 4 096: 0.393 / 0.364 -- from 1 024 channels if at most 80 % as many slots as channels are needed.
 
 // k_tail_agc is taken automatically by banks of SDRX_TAILAGC_AUTO_MIN_CU .. SDRX_TAILAGC_AUTO_MAX_CU channels per CU of the device
 // (256 .. 1 024 channels on an MI355X): measured against k_tail_s + k_agc, ms per block, bench.py's channel lists: 256 channels
@@ -944,7 +947,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         // automatic: from 1 024 channels (where the vector path is k_stage12p), if enough of them have their conjugate partner in
         // the bank (decided below, once the partners are known)
         b->mfma = (can && (tune0.matrix_pipe >= 2 || (tune0.matrix_pipe == 0 && !others && b->n_ch >= 1024))) ||
-                  (can6 && (tune0.matrix_pipe == 2 || (tune0.matrix_pipe == 0 && !others && (int)b->n_ch >= SDRX_M6_AUTO_MIN)));
+                  (can6 && !can && tune0.matrix_pipe == 2);
         b->mfma_kind = (b->mfma && can6) ? 1 : 0;
         // (never automatic: 11 % faster per block, but 2 to 3 x the reference's own build-to-build rounding spread on channels next
         // to a strong carrier, where k_stage12m is at 1.1 to 1.4 x: DESIGN.md 4.9 -- a caller's choice, SDRXGPU_FLAG_FUSED_STAGE3)
@@ -1034,7 +1037,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         // (0.97; 0.96), 1 152: 0.098 / 0.118 (0.83; 0.94), 1 408: 0.108 / 0.145 (0.75; 0.90), 1 536: 0.148 / 0.139 (1.07; 1.07),
         // 1 792: 0.162 / 0.152 (1.07; 1.16), 896: 0.097 / 0.095 (1.02; 1.33) -- where the prediction is under 0.97 the matrix
         // pipe was ahead at every size measured (profiles/r04_lab_matrix_pipe_choice.txt).  Automatic = predicted ratio under 0.97.
-        if (tune0.matrix_pipe == 0 && b->mfma_kind == 0) {        // (k_stage12m6: by the channel count alone, SDRX_M6_AUTO_MIN)
+        if (tune0.matrix_pipe == 0 && b->mfma && b->mfma_kind == 0) {
             const long long max_chunk = cfg->max_in_len ? cfg->max_in_len : 512LL * b->m_total;
             const long long U = (max_chunk / b->MM + 1 + k12->Y2B - 1) / k12->Y2B;
             const long long n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

@@ -5,7 +5,10 @@ reference is deterministic: any cut of the stream into calls, any lane length, w
 import numpy as np
 import pytest
 
-from conftest import RTOL, load_golden, regen_blocks, rel_err_rows, margin
+import glob
+import os
+
+from conftest import GOLD, RTOL, load_golden, regen_blocks, rel_err, rel_err_rows, margin
 from sdrx_amd import bank as sb, chains, synth
 
 pytestmark = pytest.mark.gpu
@@ -163,3 +166,48 @@ def test_large_bank_host_parts_multibank_and_refusals(oracle):
     with pytest.raises(sb.SdrxGpuError) as e:
         sb.ChannelBank(sb.translators_for(c24, [1, -1]), c24.stage_tuples(), tuning={"matrix_pipe": REQ})
     assert e.value.code == -5
+
+
+def test_never_automatic():
+    """A caller's choice (tuning.matrix_pipe = 2), like the fused stage 3 of the 10 MS/s chain: faster from 1 024 channels with
+    partners, but further from the reference under a strong carrier than the contract of the automatic paths allows (the stress
+    test below)."""
+    ch = chains.chain(RATE)
+    for offs in (chains.offsets_cycled(2048, ch.N), [1 + (i % 359) for i in range(2048)], chains.offsets_cycled(700, ch.N)):
+        bank = sb.ChannelBank(sb.translators_for(ch, offs), ch.stage_tuples())
+        assert int(bank.info().matrix_pipe) == 0
+        bank.close()
+    with pytest.raises(sb.SdrxGpuError):
+        sb.ChannelBank(sb.translators_for(ch, chains.offsets_cycled(64, ch.N)), ch.stage_tuples(), reference_order=True, tuning={"matrix_pipe": REQ})
+
+
+STRESS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "pairs6", "g[89]_*.npz")))
+
+
+@pytest.mark.parametrize("name", STRESS)
+def test_pairs_and_neighbours_under_a_strong_carrier(name):
+    """tests/golden/pairs6: the stress of tests/test_gpu_pairs_stress.py for this chain -- outputs of the reference compiled here (its
+    portable build and its Release build), a carrier of 0.3 / 0.9 of full scale on +37 over a floor of 0.25 / 0.05, channels: its
+    conjugate partner, a neighbour, a second pair, the untranslated one ("one"), or 35 ... 45 ("neighbours").  The vector kernels
+    (what a bank of this chain runs unless told otherwise) keep the contract of INTEGRATION.md 6: within 1e-5 of the portable build
+    wherever the reference's two builds agree to 0.5e-5, never further from it than 1.7 x their spread.  k_stage12m6 does NOT: the
+    carrier's conjugate partner under a carrier of 0.9 over a floor of 0.05 comes out 1.4e-5 from the portable build where the two
+    builds are 0.42e-5 apart -- 3.3 x; held here to 3.5 x, and that is why it is never chosen automatically."""
+    g = load_golden(name, "pairs6")
+    ch, blocks = regen_blocks(g)
+    offs = [int(o) for o in g["offsets"]]
+    tabs = [g["tables"][i] if o != 0 else None for i, o in enumerate(offs)]
+    spread_iq, spread_au = max(float(v) for v in g["avx2_rel_dev_iq"]), max(float(v) for v in g["avx2_rel_dev_audio_lf"])
+    rec = {}
+    for path, mp, times in (("matrix", REQ, 3.5), ("vector", OFF, 1.7)):
+        iq, au, info = _run(ch, tabs, blocks, tuning={"matrix_pipe": mp})
+        assert info.matrix_pipe == (1 if mp == REQ else 0)
+        e_iq = max(rel_err(iq[i], g["iq"][i]) for i in range(len(offs)))
+        e_au = max(rel_err(au[i], g["audio_lf"][i]) for i in range(len(offs)))
+        n_iq = max(min(rel_err(iq[i], g["iq"][i]), rel_err(iq[i], g["avx2_iq"][i])) for i in range(len(offs)))
+        rec[path + "_iq"], rec[path + "_audio"], rec[path + "_nearer_build_iq"] = e_iq, e_au, n_iq
+        for got, spread in ((e_iq, spread_iq), (e_au, spread_au)):
+            assert got <= max(RTOL, times * spread), (path, got, spread)
+            if spread <= 0.5e-5 and path == "vector":
+                assert got <= RTOL, (path, got, spread)
+    margin(f"pairs6[{name}]", ref_avx2_iq=spread_iq, ref_avx2_audio=spread_au, **rec)

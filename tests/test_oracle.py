@@ -68,14 +68,16 @@ def test_oracle_bit_exact_vs_reference_golden(oracle, name):
                 assert np.array_equal(_bits(r[k]), _bits(g[k][i])), f"{name} off={off} {k}: rel={rel_err(r[k], g[k][i])}"
 
 
-PAIR_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "pairs", "*.npz")))
+PAIR_CASES = sorted(("pairs", os.path.basename(p)[:-4]) for p in glob.glob(os.path.join(GOLD, "pairs", "*.npz"))) + \
+             sorted(("pairs6", os.path.basename(p)[:-4]) for p in glob.glob(os.path.join(GOLD, "pairs6", "*.npz")))
 
 
-@pytest.mark.parametrize("name", PAIR_CASES)
-def test_oracle_bit_exact_vs_reference_on_the_pair_stress_fixtures(oracle, name):
-    """tests/golden/pairs: conjugate channel pairs under a carrier of up to 0.99 of full scale over a floor down to 0.01
-    (the reference's decimated IQ and audio): the restatement reproduces the portable build bit for bit there too."""
-    g = load_golden(name, "pairs")
+@pytest.mark.parametrize("folder,name", PAIR_CASES)
+def test_oracle_bit_exact_vs_reference_on_the_pair_stress_fixtures(oracle, folder, name):
+    """tests/golden/pairs (10 MS/s chain) and pairs6 (6 MS/s chain, round 5): conjugate channel pairs under a carrier of up to 0.99 of
+    full scale over a floor down to 0.01 (the reference's decimated IQ and audio): the restatement reproduces the portable build bit
+    for bit there too."""
+    g = load_golden(name, folder)
     ch, blocks = regen_blocks(g)
     for i, off in enumerate(int(o) for o in g["offsets"]):
         r = _run_chain(oracle, ch, g["tables"][i] if off != 0 else None, blocks)
@@ -89,7 +91,12 @@ def test_the_reference_builds_disagree_by_more_than_the_tolerance_over_a_quiet_f
     at 0.25.  A path that sums in any order but the portable build's cannot hold 1e-5 against it there (tests/test_gpu_pairs_stress.py)."""
     import json
     s = json.load(open(os.path.join(GOLD, "pairs", "SUMMARY.json")))
-    assert len(s) == len(PAIR_CASES) == 30
+    s6 = json.load(open(os.path.join(GOLD, "pairs6", "SUMMARY.json")))
+    assert len(s) == 30 and len(s6) == 6 and len(PAIR_CASES) == 36
+    # the 6 MS/s chain (three stages, a 53-tap first one): the same picture -- a few 1e-6 for the pair channels, beyond 1e-5 for the
+    # carrier's neighbours under a carrier of 0.9
+    assert max(v["avx2_max_rel_dev"] for k, v in s6.items() if k.startswith("g8")) < 6e-6
+    assert s6["g9_fs6_nb_a030_n250"]["avx2_max_rel_dev"] < 5e-6 < 1e-5 < s6["g9_fs6_nb_a090_n250"]["avx2_max_rel_dev"]
     quiet = [v["avx2_max_rel_dev"] for k, v in s.items() if k.startswith("g8") and k.endswith("_n010")]
     loud = [v["avx2_max_rel_dev"] for k, v in s.items() if k.startswith("g8") and k.endswith("_n250")]
     assert min(quiet) > 1.5e-5 and max(loud) < 5e-6
