@@ -140,7 +140,9 @@ typedef struct {
                                 from the others', by rounding only): 0 = auto (banks of 1 024 channels or more whose
                                 channels mostly come in +k / -k pairs: the kernel's work goes with pairs + unpaired
                                 channels, and bank_create compares the two kernels' launch counts; with
-                                SDRXGPU_FLAG_FUSED_STAGE3: k_stage123m), 1 = never, 2 = require k_stage12m,
+                                SDRXGPU_FLAG_FUSED_STAGE3: k_stage123m), 1 = never, 2 = require k_stage12m -- or, for
+                                the 6 MS/s chain (15,53)(5,21), k_stage12m6: never automatic, 0.93 -> 0.58 ms per
+                                10 000-channel block for up to 3.4 x the reference's own rounding spread --,
                                 3 = require k_stage123m (stages 2-3 in the same kernel).  Because the automatic
                                 choice depends on the bank's channel list, a channel's last bits depend on it too -- and
                                 so on how a channel list is sharded over GPUs (<= the tolerances of INTEGRATION.md 6): pin

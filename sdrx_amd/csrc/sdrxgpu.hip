@@ -471,7 +471,7 @@ static std::atomic<int> g_banks_on_device[64];
 
 // k_stage12m6 (the 6 MS/s chain's matrix pipe) is a caller's choice, tuning.matrix_pipe = 2, never automatic: on the stress fixtures
 // of tests/golden/pairs6 (a carrier of 0.9 of full scale over a floor of 0.05) the carrier's conjugate partner comes out 1.4e-5 from
-// the reference's portable build where the reference's own two builds are 0.42e-5 apart (3.3 x their spread; k_stage12m holds 2.1 x
+// the reference's portable build where the reference's own two builds are 0.42e-5 apart (3.3 x their spread, audio 3.4 x; k_stage12m holds 2.1 x
 // on the 10 MS/s chain's fixtures, and 1e-5 wherever the builds agree to 0.5e-5) -- tests/test_gpu_matrix6.py.  Where it pays, ms
 // per block, vector / matrix (tools/lab/bench_m6_lists.py): 512 channels 0.091 / 0.123, 768: 0.121 / 0.124, 1 024: 0.130 / 0.106,
 // 2 048: 0.219 / 0.158, 4 096: 0.393 / 0.281, 10 000: 0.929 / 0.575; without partners 2 048: 0.217 / 0.201, 10 000: 0.924 / 0.952;

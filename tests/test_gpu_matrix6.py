@@ -191,15 +191,16 @@ def test_pairs_and_neighbours_under_a_strong_carrier(name):
     conjugate partner, a neighbour, a second pair, the untranslated one ("one"), or 35 ... 45 ("neighbours").  The vector kernels
     (what a bank of this chain runs unless told otherwise) keep the contract of INTEGRATION.md 6: within 1e-5 of the portable build
     wherever the reference's two builds agree to 0.5e-5, never further from it than 1.7 x their spread.  k_stage12m6 does NOT: the
-    carrier's conjugate partner under a carrier of 0.9 over a floor of 0.05 comes out 1.4e-5 from the portable build where the two
-    builds are 0.42e-5 apart -- 3.3 x; held here to 3.5 x, and that is why it is never chosen automatically."""
+    carrier's conjugate partner under a carrier of 0.9 over a floor of 0.05 comes out 1.38e-5 (IQ) / 1.78e-5 (audio) from the portable
+    build where the two builds are 0.42e-5 / 0.52e-5 apart -- 3.3 / 3.4 x; held here to 4 x, and that is why it is never chosen
+    automatically."""
     g = load_golden(name, "pairs6")
     ch, blocks = regen_blocks(g)
     offs = [int(o) for o in g["offsets"]]
     tabs = [g["tables"][i] if o != 0 else None for i, o in enumerate(offs)]
     spread_iq, spread_au = max(float(v) for v in g["avx2_rel_dev_iq"]), max(float(v) for v in g["avx2_rel_dev_audio_lf"])
     rec = {}
-    for path, mp, times in (("matrix", REQ, 3.5), ("vector", OFF, 1.7)):
+    for path, mp, times in (("matrix", REQ, 4.0), ("vector", OFF, 1.7)):
         iq, au, info = _run(ch, tabs, blocks, tuning={"matrix_pipe": mp})
         assert info.matrix_pipe == (1 if mp == REQ else 0)
         e_iq = max(rel_err(iq[i], g["iq"][i]) for i in range(len(offs)))
