@@ -58,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--tail-tile", type=int, default=0, help="tuning.tail_tile (final outputs per workgroup of the separate tail kernel), 0 auto")
     ap.add_argument("--tail-agc", type=int, default=0, help="tuning.tail_agc: 0 auto, 1 k_tail_s + k_agc, 2 require k_tail_agc (tail stages + AGC in one kernel)")
     ap.add_argument("--tail-agc-cpg", type=int, default=0, help="tuning.tail_agc_cpg (channels per workgroup of k_tail_agc), 0 auto")
+    ap.add_argument("--y2-keep-mb", type=int, default=0, help="tuning.y2_keep_mb (k_stage12m's scratch stores: 0 auto = the last 192 MB of a launch ordinary, the rest streaming; 1 = all streaming; 4294967295 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--pipelined", action="store_true",
@@ -666,9 +667,9 @@ def main():
     ch = chains.chain(args.rate)
     plan = sdist.plan(args.config, rank, world, ch.N, args.channels)
     args.tuning = None
-    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile or args.tail_agc or args.tail_agc_cpg:
+    if args.fused or args.pair or args.matrix or args.mgs or args.mgt or args.tail_tile or args.tail_agc or args.tail_agc_cpg or args.y2_keep_mb:
         args.tuning = {"fused_tail": args.fused, "pair_lanes": args.pair, "matrix_pipe": args.matrix, "m_slot_groups": args.mgs, "m_seg_groups": args.mgt,
-                       "tail_tile": args.tail_tile, "tail_agc": args.tail_agc, "tail_agc_cpg": args.tail_agc_cpg}
+                       "tail_tile": args.tail_tile, "tail_agc": args.tail_agc, "tail_agc_cpg": args.tail_agc_cpg, "y2_keep_mb": args.y2_keep_mb}
     if plan.name == "c5":
         run_c5(args, plan, ch, rank, local_rank, world, dist, torch, np, sb, sdist, synth)       # does not return
     n_ch = plan.channels_per_gpu

@@ -155,6 +155,10 @@ typedef struct {
                                 the two kernels' own latency chains are shorter than its pipeline's fill, above, its workgroups
                                 no longer fit the chip at once: DESIGN.md 4.10), 1 = never, 2 = require                  */
     uint32_t tail_agc_cpg;   /*   channels per workgroup of that kernel: 1, 2 or 4; 0 = auto                           */
+    uint32_t y2_keep_mb;     /* k_stage12m's scratch stores: the sets of a launch written last -- this many MB + 1 of stage-2
+                                outputs -- are ordinary stores (the tail kernel reads them first, out of the Infinity Cache),
+                                everything before them goes out with the streaming hint (same bits):
+                                0 = auto (192 MB), 1 = everything streams, 0xFFFFFFFF = nothing does                   */
 } sdrxgpu_tuning;
 
 typedef struct {

@@ -48,7 +48,7 @@ class AgcParams(C.Structure):
 class Tuning(C.Structure):
     """sdrxgpu_tuning: geometry / kernel-path overrides for tests and tuning runs (0 = automatic)."""
     _fields_ = [(k, C.c_uint32) for k in ("struct_size", "k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail", "host_parts",
-                                            "pair_lanes", "matrix_pipe", "m_slot_groups", "m_seg_groups", "tail_agc", "tail_agc_cpg")]
+                                            "pair_lanes", "matrix_pipe", "m_slot_groups", "m_seg_groups", "tail_agc", "tail_agc_cpg", "y2_keep_mb")]
 
     def __init__(self, **kw):
         kw.setdefault("struct_size", C.sizeof(Tuning))

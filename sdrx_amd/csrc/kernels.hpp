@@ -381,6 +381,8 @@ struct Stage12Args {
     int c0;
     int n_y3;
     int seam_stride;        // float2 per channel of the seam buffer: [range][2][TA-1] (first / last TA-1 outputs of each range)
+    // k_stage12m: slot-group sets below this one store their stage-2 outputs with the streaming hint (`nt`); 0: none
+    int nt_sets = 0;
 };
 
 // LDS tile geometry.  A wave's 64 lanes are CPW channels x SPW = 64/CPW time segments (lane =
@@ -1368,8 +1370,13 @@ __device__ __forceinline__ void tail_s_unit(const TailArgs &a, const int ch, con
         int sa2, sb2;
         const float2 *sa = group_src(ia, sa2), *sb = group_src(ib, sb2);
         if (G == 4) {
+#ifdef SDRX_LAB_TAIL_LD_NT                                  // lab: streaming loads of the stage-2 scratch
+            const v4f a0 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(sa)), a1 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(sa + sa2));
+            const v4f b0 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(sb)), b1 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(sb + sb2));
+#else
             const v4f a0 = *reinterpret_cast<const v4f *>(sa), a1 = *reinterpret_cast<const v4f *>(sa + sa2);
             const v4f b0 = *reinterpret_cast<const v4f *>(sb), b1 = *reinterpret_cast<const v4f *>(sb + sb2);
+#endif
             if (ia < ngrp) { s2v[2 * ia] = a0; s2v[2 * ia + 1] = a1; }
             if (ib < ngrp) { s2v[2 * ib] = b0; s2v[2 * ib + 1] = b1; }
         } else {

@@ -97,6 +97,7 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         wtm = w % a.n_wt;
         cgm = a.cg0 + (n_sets & ~7) + w / a.n_wt;
     }
+    const bool y2_stream = cgm < a.nt_sets;
     const int gq = wtm / a.P, p = wtm - gq * a.P;
     const int bps = a.nb * a.P;
     const int g_first = gq * GT;                            // first segment group of the workgroup
@@ -252,9 +253,22 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
         const uint32_t at = ylane + (uint32_t)(2 * body + h) * SPW * 2;
         // (scalar base + 32-bit byte offset per lane: one address register per store -- these stores sit between the phases now,
         // where the register file is full; the host keeps the scratch below 4 GB)
+        // y2_stream: a scratch larger than the Infinity Cache goes out with the streaming hint, except the sets written last, which the
+        // tail kernel reads first (tail 0.243 -> 0.231 ms at 10 000 channels with every store streaming; 0.044 -> 0.049
+        // at 1 024 channels, whose scratch the cache holds)
+        if (y2_stream) {
 #pragma unroll
-        for (int i = i0; i < i1; i++)
-            *reinterpret_cast<v4f *>(reinterpret_cast<char *>(y2_out) + (size_t)((yrow[i] + at) * 8u)) = stage[i];
+            for (int i = i0; i < i1; i++)
+                // Inline assembly, because LLVM folds the two arms of this branch into one ordinary store otherwise (also with
+                // __builtin_nontemporal_store in this one).  The s_nop is the compiler's own rule for gfx940 and later, which it cannot
+                // apply to a store it does not see: two wait states between a store of more than 8 bytes and a vector instruction
+                // that overwrites its data registers (without it one set of a 2 304-channel bank came out wrong).
+                asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"((yrow[i] + at) * 8u), "v"(stage[i]), "s"(y2_out) : "memory");
+        } else {
+#pragma unroll
+            for (int i = i0; i < i1; i++)
+                *reinterpret_cast<v4f *>(reinterpret_cast<char *>(y2_out) + (size_t)((yrow[i] + at) * 8u)) = stage[i];
+        }
     };
     auto store_staged = [&](int body, int h) { store_staged_part(body, h, 0, 8); };
     // combinations + stage 2 for stage-1 output P20 (0..19) of a body

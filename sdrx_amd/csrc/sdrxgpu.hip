@@ -469,6 +469,12 @@ static long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) 
 #include <atomic>
 static std::atomic<int> g_banks_on_device[64];
 
+// k_stage12m's scratch stores: the last SDRX_Y2_KEEP_MB of a launch's stage-2 outputs stay ordinary stores (they are still in the
+// 256 MB Infinity Cache when the tail kernel reads them, which it does first), everything before them streams (launch_k12_parts)
+#ifndef SDRX_Y2_KEEP_MB
+#define SDRX_Y2_KEEP_MB 192
+#endif
+
 // k_stage12m6 (the 6 MS/s chain's matrix pipe) is a caller's choice, tuning.matrix_pipe = 2, never automatic: on the stress fixtures
 // of tests/golden/pairs6 (a carrier of 0.9 of full scale over a floor of 0.05) the carrier's conjugate partner comes out 1.4e-5 from
 // the reference's portable build where the reference's own two builds are 0.42e-5 apart (3.3 x their spread, audio 3.4 x; k_stage12m holds 2.1 x
@@ -616,6 +622,7 @@ struct sdrxgpu_bank {
     std::vector<int> part_g;                          // slot-group boundaries of the parts
     hipStream_t copy_stream = nullptr;
     int host_parts = 0;                               // tuning.host_parts (0 = auto)
+    size_t y2_keep = 0;                               // bytes of a k_stage12m launch's scratch (the sets written last) stored without the streaming hint
     hipEvent_t ev_part[8] = {};                       // kernels of a channel part are done
     hipEvent_t ev_h2d = nullptr;                      // the block is in the input ring
     hipEvent_t ev_d2h = nullptr;                      // the output rows have left the keep buffers
@@ -1104,6 +1111,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.host_parts %u (0..8)", tune.host_parts);
     }
     b->host_parts = (int)tune.host_parts;
+    b->y2_keep = tune.y2_keep_mb == 0 ? (size_t)SDRX_Y2_KEEP_MB << 20 : tune.y2_keep_mb == 0xFFFFFFFFu ? ~(size_t)0 : (size_t)(tune.y2_keep_mb - 1) << 20;
     {
         const int tB = (int)b->ntaps[cfg->n_stages - 1], mB = (int)b->m[cfg->n_stages - 1];
         size_t np, nr = 0;
@@ -1958,6 +1966,14 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
         M.pa.n_slots = whole ? b->n_slots_m : b->n_slots_mp;
         M.kind = b->mfma_kind;
         M.pa.lds_bytes = (int)k12m_lds_bytes(b->mfma_kind, b->mGS, b->mGT);
+        if (b->mfma_kind == 0) {
+            // The scratch rows of all but the sets written last go out with the streaming hint: what the Infinity Cache cannot hold until
+            // the tail kernel comes for it should not push out what it can (the tail starts with the rows written last).
+            const size_t keep = b->y2_keep;
+            const size_t set_bytes = (size_t)32 * b->mGS * (size_t)M.L.args.n_y2_new * sizeof(float2);
+            const long long keep_sets = set_bytes ? (long long)(keep / set_bytes) : 0;
+            M.L.args.nt_sets = (int)std::max<long long>(0, (long long)g_hi - keep_sets);
+        }
         if ((uint64_t)(b->n_ch + 1) * (uint64_t)b->y2_stride * sizeof(float2) >= (1ull << 32))
             return fail(SDRXGPU_ERR_HIP, "internal: stage-2 scratch of %u x %d entries exceeds k_stage12m's 32-bit byte offsets", b->n_ch, b->y2_stride);
         HIPCHK(launch_k12m(M, st));

@@ -47,6 +47,7 @@ while time.time() < t_end:
     lf = rng.random() < 0.3
     gs, gt = rng.choice([(0, 0), (2, 2), (4, 2), (2, 4)])
     hint = rng.choice([0, 0, WHOLE, 1, 2, 3, 4, 6])
+    keep = rng.choice([0, 1, 1 + rng.randrange(0, 40), 0xFFFFFFFF])      # tuning.y2_keep_mb: which sets' scratch stores stream (same bits)
 
     def run(tuning, hint_, blocks):
         b = sb.ChannelBank(tabs, ch.stage_tuples(), block_hint=hint_, lf_agc=lf, ftfir=ftfir, tuning=tuning)
@@ -54,8 +55,8 @@ while time.time() < t_end:
         outs = [b.process(x) for x in blocks]
         b.close()
         return np.concatenate([o[0] for o in outs], 1), np.concatenate([o[1] for o in outs], 1), info
-    ref = run({"matrix_pipe": 2}, 0, whole)
-    got = run({"matrix_pipe": 2, "m_slot_groups": gs, "m_seg_groups": gt}, hint, cuts)
+    ref = run({"matrix_pipe": 2, "y2_keep_mb": 0xFFFFFFFF}, 0, whole)
+    got = run({"matrix_pipe": 2, "m_slot_groups": gs, "m_seg_groups": gt, "y2_keep_mb": keep}, hint, cuts)
     vec = run({"matrix_pipe": 1}, 0, whole)
     assert ref[2].matrix_pipe == 1 and got[2].matrix_pipe == 1 and vec[2].matrix_pipe == 0
     ok = np.array_equal(ref[0].view(np.uint32), got[0].view(np.uint32)) and np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32))
@@ -69,7 +70,7 @@ while time.time() < t_end:
         errs.append(float(np.max(np.abs(got[0][c, :len(y)] - y) / d)) if len(y) else 0.0)
     n_cases += 1
     good = ok and max(errs) < 1e-5 and e_vec < 1e-5
-    print(("OK  " if good else "FAIL"), "ftfir" if ftfir else "     ", "n_ch", n_ch, kind, "hint", hint, "shape", (gs, gt), "lf", lf, "calls", len(cuts),
+    print(("OK  " if good else "FAIL"), "ftfir" if ftfir else "     ", "n_ch", n_ch, kind, "hint", hint, "shape", (gs, gt), "keep", keep, "lf", lf, "calls", len(cuts),
           "slots", got[2].m_slots, "oracle %.2e" % max(errs), "vector kernels %.2e" % e_vec, flush=True)
     if not good:
         sys.exit(1)

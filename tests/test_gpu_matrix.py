@@ -108,6 +108,26 @@ def test_workgroup_shapes_and_lane_lengths_give_the_same_bits(gs, gt):
         assert np.array_equal(want[1].view(np.uint32), got[1].view(np.uint32))
 
 
+@pytest.mark.parametrize("gs,gt", [(2, 2), (4, 2), (2, 4)])
+def test_streaming_scratch_stores_give_the_same_bits(gs, gt):
+    """k_stage12m writes the stage-2 scratch of all but the sets written last with the streaming hint (tuning.y2_keep_mb; automatic:
+    the last 192 MB of a launch stay ordinary stores).  A cache policy, not arithmetic: everything streaming, nothing streaming, a cut
+    in the middle of the bank (the streaming arm is inline assembly behind a branch per workgroup) -- the same bits, over ragged calls."""
+    ch = chains.chain("10")
+    offs = chains.offsets_cycled(300, ch.N) + [0, 7, 7]
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    stream = synth.synth_iq(91, 0, L + 40000, 0.25, [tabs[3]], [0.3], ch.N, 10000)
+    lens = [L, 625, 10 ** 9]
+    shape = {"m_slot_groups": gs, "m_seg_groups": gt}
+    want = _run(ch, tabs, _cut(stream, lens), tuning=dict(shape, y2_keep_mb=0xFFFFFFFF))
+    # (a set of 32 x gs rows x 12 800 new outputs x 8 B is 6.5 MB at gs = 2: "keep 14 MB" leaves the last two sets ordinary)
+    for keep in (1, 1 + 14, 0):
+        got = _run(ch, tabs, _cut(stream, lens), tuning=dict(shape, y2_keep_mb=keep))
+        assert np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32)), keep
+        assert np.array_equal(want[1].view(np.uint32), got[1].view(np.uint32)), keep
+
+
 def test_a_channels_bits_do_not_depend_on_who_else_is_in_the_bank():
     ch = chains.chain("10")
     L = ch.block_len
