@@ -355,7 +355,10 @@ int sdrxgpu_multibank_destroy(sdrxgpu_multibank *mb);
 int sdrxgpu_multibank_reset(sdrxgpu_multibank *mb);
 
 /* sdrxgpu_bank_process over all devices: HOST pointers, outputs complete in caller memory on return.  A refused call
- * (out_stride too small, ...) is refused before any device has been touched. */
+ * (out_stride too small, ...) is refused before any device has been touched.  A call that fails ON a device (a HIP
+ * error: the code and text name the shard) can leave the shards at different places of the stream:
+ * sdrxgpu_multibank_reset (or destroy) before going on.  Like a bank, a multibank is driven by ONE thread at a time
+ * (data_cb's, sdrx.cpp:306): its calls are not reentrant; different multibanks are independent. */
 int sdrxgpu_multibank_process(sdrxgpu_multibank *mb, const sdrxgpu_iq *iq_in, size_t in_len, sdrxgpu_iq *iq_out,
                               float *audio_out, size_t out_stride, size_t *out_len);
 /* sdrxgpu_bank_process_pinned over all devices: page-locked host block in, per-shard DEVICE output pointers
