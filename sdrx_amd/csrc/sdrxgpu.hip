@@ -2330,6 +2330,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
             p.max_gain = s.max_gain;
             p.min_gain = (s.max_gain > 0.0f) ? 1.0f / s.max_gain : 1.0f / 200.0f;   // agc.hpp:34, 42
             p.alpha = s.alpha;
+            p.sel = (s.decay <= s.attack) ? -INFINITY : INFINITY;
         };
         fill(g.agc, b->agc);
         fill(g.lf, b->lf);

@@ -490,6 +490,38 @@ def test_lf_agc_and_custom_agc_parameters(oracle):
     assert rel_err(au, ref) <= RTOL
 
 
+@pytest.mark.parametrize("rates", [(1.0, 0.01), (0.02, 0.5), (0.3, 0.3), (0.0, 0.2)])
+def test_agc_rates_in_either_order(oracle, rates):
+    """The kernels take the gain update `gain += (err > 0 ? decay : attack) * err` (agc.hpp:56-61) without the compare: as the smaller
+    (decay <= attack) or the larger (decay > attack) of the two fmas.  Held against the oracle's compare-and-select for both orders,
+    equal rates and a zero rate, IF and LF loop with opposite orders, a carrier that comes and goes (err of both signs), through
+    k_agc and through k_tail_agc."""
+    att, dec = rates
+    ch = chains.chain("10")
+    offs = [5, -5, 6, 0]
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    blocks = [synth.synth_iq(31, b * L, L, 0.02, [tabs[0]], [0.0 if b == 1 else 0.6], ch.N, 10000) for b in range(3)]
+    agc, lf = sb.sdrx_agc_params()
+    agc.attack, agc.decay = att, dec
+    lf.attack, lf.decay = dec, att
+    for ta in (1, 2):
+        bank = sb.ChannelBank(tabs, ch.stage_tuples(), lf_agc=True, agc=agc, agc_lf=lf, tuning={"tail_agc": ta})
+        assert (bank.info().tail_agc > 0) == (ta == 2)
+        outs = [bank.process(x) for x in blocks]
+        bank.close()
+        iq = np.concatenate([o[0] for o in outs], axis=1)
+        au = np.concatenate([o[1] for o in outs], axis=1)
+        worst = 0.0
+        for c in range(len(offs)):
+            pair = oracle.agc_pair(True)
+            pair.agc.attack, pair.agc.decay, pair.lf.attack, pair.lf.decay = att, dec, dec, att
+            ref = pair.adjust_lf(oracle.demod_am(pair.adjust(iq[c])))      # (the oracle's loops on the GPU's own decimated IQ)
+            worst = max(worst, rel_err(au[c], ref))
+        margin(f"agc_rates[{att},{dec},tail_agc={ta}]", audio=worst)
+        assert worst <= RTOL, (rates, ta, worst)
+
+
 def test_squelch_and_gated_audio_vs_oracle(oracle):
     """Squelch (sdrx.cpp:533-573) + the audio gating by it (458-503) over a carrier that comes and goes: closed ->
     opening (ramp_up) -> open -> closing (ramp_down) -> closed, plus an always-open (level 0) and a never-opening channel.
