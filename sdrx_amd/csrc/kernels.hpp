@@ -334,6 +334,54 @@ __device__ __forceinline__ void folded_fir3_steps(v2f &a0, v2f &a1, v2f &a2, con
     }
 }
 
+// folded_fir_ahead for THREE windows at once (k_tail_agc's A-waves: with three alternating chains no packed FMA reads the result of
+// the one before it).  Per output the same operands in the same order as folded_fir_ahead / folded_fir_unrolled: same bits.
+template <int T, int NH, int D, int I = 0>
+__device__ __forceinline__ void folded_fir3_ahead_steps(v2f &a0, v2f &a1, v2f &a2, v2f (&lo0)[D], v2f (&hi0)[D], v2f (&lo1)[D], v2f (&hi1)[D],
+                                                        v2f (&lo2)[D], v2f (&hi2)[D], const v2f *__restrict__ w0, const v2f *__restrict__ w1,
+                                                        const v2f *__restrict__ w2, const float (&h)[NH])
+{
+    constexpr int half = (T - 1) >> 1;
+    if constexpr (I <= half) {
+        const v2f hp = {h[I & ~1], h[(I & ~1) + 1]};
+        if constexpr (I < half) {
+            const v2f s0 = lo0[I % D] + hi0[I % D], s1 = lo1[I % D] + hi1[I % D], s2 = lo2[I % D] + hi2[I % D];
+            if constexpr (I + D < half) {
+                lo0[I % D] = lds_read_here(w0 + I + D); hi0[I % D] = lds_read_here(w0 + T - 1 - I - D);
+                lo1[I % D] = lds_read_here(w1 + I + D); hi1[I % D] = lds_read_here(w1 + T - 1 - I - D);
+                lo2[I % D] = lds_read_here(w2 + I + D); hi2[I % D] = lds_read_here(w2 + T - 1 - I - D);
+            } else if constexpr (I + D == half) {
+                lo0[I % D] = lds_read_here(w0 + half);
+                lo1[I % D] = lds_read_here(w1 + half);
+                lo2[I % D] = lds_read_here(w2 + half);
+            }
+            fma_tap3<I>(a0, a1, a2, s0, s1, s2, hp);
+        } else {
+            fma_tap3<I>(a0, a1, a2, lo0[I % D], lo1[I % D], lo2[I % D], hp);
+        }
+        folded_fir3_ahead_steps<T, NH, D, I + 1>(a0, a1, a2, lo0, hi0, lo1, hi1, lo2, hi2, w0, w1, w2, h);
+    }
+}
+
+template <int T, int NH, int D>
+__device__ __forceinline__ void folded_fir3_ahead(v2f &r0, v2f &r1, v2f &r2, const v2f *__restrict__ w0, const v2f *__restrict__ w1,
+                                                  const v2f *__restrict__ w2, const float (&h)[NH])
+{
+    constexpr int half = (T - 1) >> 1;
+    static_assert(D >= 1 && D <= half, "prefetch distance in tap pairs");
+    v2f lo0[D], hi0[D], lo1[D], hi1[D], lo2[D], hi2[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        lo0[i] = lds_read_here(w0 + i); hi0[i] = lds_read_here(w0 + T - 1 - i);
+        lo1[i] = lds_read_here(w1 + i); hi1[i] = lds_read_here(w1 + T - 1 - i);
+        lo2[i] = lds_read_here(w2 + i); hi2[i] = lds_read_here(w2 + T - 1 - i);
+    }
+    r0 = v2f{0.f, 0.f};
+    r1 = v2f{0.f, 0.f};
+    r2 = v2f{0.f, 0.f};
+    folded_fir3_ahead_steps<T, NH, D>(r0, r1, r2, lo0, hi0, lo1, hi1, lo2, hi2, w0, w1, w2, h);
+}
+
 // Two outputs whose windows w0 and w1 both lie in LDS (any distance apart): nothing is shared between them but the
 // taps and the instruction slots -- the point is the alternating accumulation chains of fma_tap2.
 template <int T, int NH>

@@ -155,14 +155,25 @@ __global__ __launch_bounds__((2 * NC + 2) * kWave) void k_tail_agc(const TailAgc
                         const v2f *s2 = reinterpret_cast<const v2f *>(cbase + (k % G::NBUF) * G::S2N) + lead;
                         v2f *s3 = reinterpret_cast<v2f *>(s3base + (k & 1) * G::S3N);
 #ifndef SDRX_LAB_TA_NOFIR
-                        // two outputs per lane and pass (r and r + 64: two independent accumulation chains -- the wave is alone on its
-                        // SIMD, nothing else fills the wait between two dependent instructions); per output folded_fir_ahead's arithmetic
-                        for (int r = lane; r < nr; r += 2 * kWave) {
-                            const int r1 = min(r + kWave, nr - 1);                 // (past the end: the last output once more, not stored)
-                            v2f o0, o1;
-                            folded_fir2_ahead<TA, kMaxHalfTaps, SDRX_FIR_AHEAD_A>(o0, o1, s2 + MA * r, s2 + MA * r1, t.hA);
-                            s3[r] = o0;
-                            if (r + kWave < nr) s3[r + kWave] = o1;
+                        // The first TB - MB stage-A outputs of tile k are the last ones of tile k-1 (stage B's window reaches back over
+                        // them): copied from the other buffer, not computed again (28 % of a tile's stage-A outputs).  The new ones:
+                        // three per lane and pass (r, r + 64, r + 128: three independent accumulation chains -- the wave has its SIMD
+                        // to itself or shares it with two others, nothing else fills the wait between two dependent instructions); one
+                        // pass per full tile.  Per output folded_fir_ahead's arithmetic on the same operands: the same bits.
+                        constexpr int CARRY = TB - MB;
+                        int r_first = 0;
+                        if (k > 0) {
+                            const v2f *s3p = reinterpret_cast<const v2f *>(s3base + ((k - 1) & 1) * G::S3N) + MB * kAgcTile;
+                            for (int i = lane; i < CARRY; i += kWave) s3[i] = s3p[i];
+                            r_first = CARRY;
+                        }
+                        for (int rb = r_first + lane; rb < nr; rb += 3 * kWave) {
+                            const int r1 = min(rb + kWave, nr - 1), r2 = min(rb + 2 * kWave, nr - 1);   // (past the end: the last output once more, not stored)
+                            v2f o0, o1, o2;
+                            folded_fir3_ahead<TA, kMaxHalfTaps, SDRX_FIR_AHEAD_A>(o0, o1, o2, s2 + MA * rb, s2 + MA * r1, s2 + MA * r2, t.hA);
+                            s3[rb] = o0;
+                            if (rb + kWave < nr) s3[rb + kWave] = o1;
+                            if (rb + 2 * kWave < nr) s3[rb + 2 * kWave] = o2;
                         }
 #endif
                     }
