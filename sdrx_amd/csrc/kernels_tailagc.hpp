@@ -154,12 +154,11 @@ __global__ __launch_bounds__((2 * NC + 2) * kWave) void k_tail_agc(const TailAgc
                         span(k, nbt, nr, p0g, lead);
                         const v2f *s2 = reinterpret_cast<const v2f *>(cbase + (k % G::NBUF) * G::S2N) + lead;
                         v2f *s3 = reinterpret_cast<v2f *>(s3base + (k & 1) * G::S3N);
-#ifndef SDRX_LAB_TA_NOFIR
+#if !defined(SDRX_LAB_TA_NOFIR) && !defined(SDRX_LAB_TA_NOFIR_A)
                         // The first TB - MB stage-A outputs of tile k are the last ones of tile k-1 (stage B's window reaches back over
                         // them): copied from the other buffer, not computed again (28 % of a tile's stage-A outputs).  The new ones:
-                        // three per lane and pass (r, r + 64, r + 128: three independent accumulation chains -- the wave has its SIMD
-                        // to itself or shares it with two others, nothing else fills the wait between two dependent instructions); one
-                        // pass per full tile.  Per output folded_fir_ahead's arithmetic on the same operands: the same bits.
+                        // three per lane, one pass per full tile.  Per output folded_fir_unrolled's arithmetic on the same operands:
+                        // the same bits.
                         constexpr int CARRY = TB - MB;
                         int r_first = 0;
                         if (k > 0) {
@@ -167,13 +166,20 @@ __global__ __launch_bounds__((2 * NC + 2) * kWave) void k_tail_agc(const TailAgc
                             for (int i = lane; i < CARRY; i += kWave) s3[i] = s3p[i];
                             r_first = CARRY;
                         }
-                        for (int rb = r_first + lane; rb < nr; rb += 3 * kWave) {
-                            const int r1 = min(rb + kWave, nr - 1), r2 = min(rb + 2 * kWave, nr - 1);   // (past the end: the last output once more, not stored)
-                            v2f o0, o1, o2;
-                            folded_fir3_ahead<TA, kMaxHalfTaps, SDRX_FIR_AHEAD_A>(o0, o1, o2, s2 + MA * rb, s2 + MA * r1, s2 + MA * r2, t.hA);
+                        for (int rb = r_first + 3 * lane; rb < nr; rb += 3 * kWave) {
+                            // three NEIGHBOURING outputs per lane: their windows overlap, TA + 2 MA entries are read where three separate
+                            // windows take 3 TA (this kernel's waves run out of LDS cycles before anything else: four channels' stage A
+                            // and B per CU), and three independent accumulation chains (fma_tap3).  An output past the end works on
+                            // entries inside the buffer and is not stored.
+                            v2f win[TA + 2 * MA];
+                            const v2f *w = s2 + MA * rb;
+#pragma unroll
+                            for (int j = 0; j < TA + 2 * MA; j++) win[j] = w[j];
+                            v2f o0 = {0.f, 0.f}, o1 = {0.f, 0.f}, o2 = {0.f, 0.f};
+                            folded_fir3_steps<TA>(o0, o1, o2, win, win + MA, win + 2 * MA, t.hA);
                             s3[rb] = o0;
-                            if (rb + kWave < nr) s3[rb + kWave] = o1;
-                            if (rb + 2 * kWave < nr) s3[rb + 2 * kWave] = o2;
+                            if (rb + 1 < nr) s3[rb + 1] = o1;
+                            if (rb + 2 < nr) s3[rb + 2] = o2;
                         }
 #endif
                     }
@@ -200,6 +206,26 @@ __global__ __launch_bounds__((2 * NC + 2) * kWave) void k_tail_agc(const TailAgc
                 int nbt, nr, p0g, lead;
                 span(i, nbt, nr, p0g, lead);
                 char *dst = reinterpret_cast<char *>(cbase + (i % G::NBUF) * G::S2N);
+                // A span that lies wholly among the call's new outputs and inside the row (every tile but the first one or two and the
+                // last) needs none of the clamps and selects below: pair 64 r + l is group (first + 2 l + 128 r) >> gsh of the table,
+                // its half of the group the same for every r -- one table read and one add per DMA instruction (the general form below
+                // was 1 060 of a B-wave's 2 550 cycles per tile).
+                if (p0g >= t.hist && p0g + 2 * (G::RD * kWave - 1) <= p_lastpair) {
+                    const int j0 = p0g - t.hist + 2 * lane;
+                    const uint32_t off2 = (Gsz == 4 && (j0 & 2)) ? (uint32_t)pair2 : 0u;
+                    const uint32_t *gp = gtab + (j0 >> gsh);
+                    const int gstep = (2 * kWave) >> gsh;
+                    uint32_t e[G::RD];
+#pragma unroll
+                    for (int r = 0; r < G::RD; r++) e[r] = (gp[r * gstep] + off2) * (uint32_t)sizeof(float2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < G::RD; r++)
+                        __builtin_amdgcn_global_load_lds((gbl_void *)(uintptr_t)(reinterpret_cast<const char *>(ynew) + e[r]),
+                                                         (lds_void *)(uint32_t)(uintptr_t)(dst + r * kWave * 16), 16, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    return;
+                }
                 uintptr_t src[G::RD];
 #pragma unroll
                 for (int r = 0; r < G::RD; r++) {
@@ -234,7 +260,7 @@ __global__ __launch_bounds__((2 * NC + 2) * kWave) void k_tail_agc(const TailAgc
                     const v2f *bsrc = HAS_A ? reinterpret_cast<const v2f *>(s3base + (tb & 1) * G::S3N)
                                             : reinterpret_cast<const v2f *>(cbase + (tb % G::NBUF) * G::S2N) + lead;
                     if (lane < nbt) {
-#ifndef SDRX_LAB_TA_NOFIR
+#if !defined(SDRX_LAB_TA_NOFIR) && !defined(SDRX_LAB_TA_NOFIR_B)
                         const v2f r = folded_fir_ahead<TB, kMaxHalfTaps, SDRX_FIR_AHEAD_B>(bsrc + MB * lane, t.hB);
 #else
                         const v2f r = bsrc[lane];

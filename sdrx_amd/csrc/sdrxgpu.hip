@@ -1300,10 +1300,12 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         }
         const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         // 1, 2 or 4 channels per workgroup (two producer waves each + the two AGC waves): as few as still give every CU at most one
-        // workgroup; tuning.tail_agc_cpg sets it instead.
-        // (2: at 768 channels 4 were 2.5 % faster, at 1 024 the same -- but a workgroup of 4 channels holds 150 KB of LDS, a CU then has
-        // room for nothing else, and two banks on one GPU (BASELINE configs[4]) lost 15 % of their overlap: 0.219 against 0.190 ms)
-        b->ta_nt = (int)b->n_ch <= n_cu / 2 ? 1 : 2;
+        // workgroup; tuning.tail_agc_cpg sets it instead.  Measured (tools/lab/bench_ta_cpg.sh, the kernel's us with 1 / 2 / 4): 256
+        // channels 30.6 / 32.0 / 36.5, 384: 33.9 / 32.0 / 35.6, 512: 34.2 / 32.0 / 35.8, 768: 45.2 / 40.4 / 37.6, 1 024: 67.5 / 41.6 /
+        // 37.8.  (A workgroup of 4 channels holds 150 KB of LDS and a CU then has room for nothing else -- which cost two banks on one
+        // GPU, BASELINE configs[4], 15 % of their overlap while the kernel was chosen per bank; it now runs only while its bank is
+        // alone on the device, launch_tail.)
+        b->ta_nt = (int)b->n_ch <= n_cu ? 1 : (int)b->n_ch <= 2 * n_cu ? 2 : 4;
         if (tune.tail_agc_cpg) {
             if (tune.tail_agc_cpg != 1 && tune.tail_agc_cpg != 2 && tune.tail_agc_cpg != 4) {
                 free_bank(b);

@@ -159,7 +159,8 @@ def test_refusals_and_automatic_choice():
         sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"tail_agc_cpg": 3})
     assert e.value.code == -1
     # automatic where it is the faster of the two: mid-size banks
-    for n, want in ((64, 0), (512, 2), (1024, 2), (2048, 0)):
+    # (channels per workgroup: as few as give every CU of the 256 one workgroup at most)
+    for n, want in ((64, 0), (256, 1), (512, 2), (1024, 4), (2048, 0)):
         bk = sb.ChannelBank(sb.translators_for(ch, chains.offsets_cycled(n, ch.N)), ch.stage_tuples())
         assert bk.info().tail_agc == want, (n, bk.info().tail_agc)
         bk.close()
