@@ -1438,6 +1438,10 @@ __device__ __forceinline__ void tail_s_unit(const TailArgs &a, const int ch, con
 
     const v2f *bsrc = s2;
     if constexpr (HAS_A) {
+        // (two neighbouring outputs per lane from one register window of TA + MA entries -- 26 LDS reads for two outputs instead of 84, one
+        // pass of 191 lanes per tile -- measured SLOWER here, 0.2335 against 0.2285 ms at 10 000 channels, 0.0474 / 0.0453 at 2 048: 58
+        // registers instead of 28, and this kernel lives on the number of workgroups whose loads are in flight; in k_tail_agc, whose
+        // waves are few and long-lived, the same change pays: kernels_tailagc.hpp)
         for (int r = tid; r < nr; r += 256) s3[r] = folded_fir_ahead<TA, kMaxHalfTaps, SDRX_FIR_AHEAD_A>(s2 + MA * r, a.hA);
         __syncthreads();
         bsrc = s3;
