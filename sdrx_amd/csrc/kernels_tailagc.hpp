@@ -100,6 +100,10 @@ __global__ __launch_bounds__((2 * NC + 2) * kWave) void k_tail_agc(const TailAgc
         for (int i = threadIdx.x; i < g.roll_cnt; i += NTHREADS) g.roll_to[i] = g.roll_from[i];
         return;
     }
+    // (Waves w and w + 4 of a workgroup share a SIMD -- probed: s_getreg HW_ID.  Giving the IF and the LF wave a SIMD of their own, the
+    // producers the other three (4 channels per workgroup), measured SLOWER, 43.4 against 37.8 us at 1 024 channels; IF and LF each
+    // alone on a SIMD (2 channels per workgroup) 32.9 against 32.5: the recurrence is not held up by its neighbours' instructions, it
+    // is the pipeline's pace itself -- 19 iterations of a 32-step chain.)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & (kWave - 1);
     const int ch0 = t.ch_lo + blockIdx.x * NC;
