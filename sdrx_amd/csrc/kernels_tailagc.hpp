@@ -84,12 +84,18 @@ __device__ __forceinline__ void wg_barrier_lds()
 //            waits until the span of tile k+1 (asked for an iteration ago) has landed: the A-wave reads it after the barrier
 //   A-wave   stage A of tile k: span ring k % 3 -> stage-A buffer k & 1
 //   IF wave  tile k-2;  LF wave  tile k-3
+// A-waves of a workgroup of NC channels: one per channel, or -- four channels -- one per two (stage A is a pass of 54 lanes per tile
+// and channel since its second version; eight waves on the CU's four SIMDs instead of ten)
+constexpr int tail_agc_a_waves(int nc) { return nc >= 4 ? nc / 2 : nc; }
+constexpr int tail_agc_waves(int nc) { return tail_agc_a_waves(nc) + nc + 2; }
+
 template <int MA, int TA, int MB, int TB, bool SQ, bool FM, int NC>
-__global__ __launch_bounds__((2 * NC + 2) * kWave) void k_tail_agc(const TailAgcArgs a)
+__global__ __launch_bounds__(tail_agc_waves(NC) * kWave) void k_tail_agc(const TailAgcArgs a)
 {
     using G = TailAgcGeom<MA, TA, MB, TB>;
     constexpr bool HAS_A = G::HAS_A;
-    constexpr int NTHREADS = (2 * NC + 2) * kWave;
+    constexpr int NA = tail_agc_a_waves(NC);
+    constexpr int NTHREADS = tail_agc_waves(NC) * kWave;
     extern __shared__ __attribute__((aligned(16))) char ta_smem[];
     TailAgcLds<FM, NC> &L = *reinterpret_cast<TailAgcLds<FM, NC> *>(ta_smem);
     const TailArgs &t = a.t;
@@ -139,21 +145,25 @@ __global__ __launch_bounds__((2 * NC + 2) * kWave) void k_tail_agc(const TailAgc
         lead = p0 - p0g;
     };
 
-    if (wave < 2 * NC) {
-        const bool is_b = wave >= NC;
-        const int cl = is_b ? wave - NC : wave;                     // channel within the workgroup
+    if (wave < NA + NC) {
+        const bool is_b = wave >= NA;
+        const int cl = is_b ? wave - NA : wave;                     // channel within the workgroup (an A-wave's first one)
         const bool live = cl < n_here;
         const int ch = ch0 + min(cl, n_here - 1);
         float2 *cbase = reinterpret_cast<float2 *>(ta_smem + sizeof(TailAgcLds<FM, NC>) + (size_t)cl * G::chan_lds);
         float2 *s3base = cbase + G::NBUF * G::S2N;
         if (!is_b) {
             // --------------------------------------------------------------------------------------------------------
-            // A-wave: stage A of tile k in iteration k
+            // A-wave: stage A of tile k in iteration k, for the channels wave, wave + NA, ... of the workgroup
             // --------------------------------------------------------------------------------------------------------
             wg_barrier_lds();
             for (int k = 0; k < n_iter; k++) {
                 if constexpr (HAS_A) {
-                    if (live && k < n_tiles) {
+#pragma unroll
+                    for (int ca = wave; ca < NC; ca += NA)
+                    if (ca < n_here && k < n_tiles) {
+                        float2 *cbase = reinterpret_cast<float2 *>(ta_smem + sizeof(TailAgcLds<FM, NC>) + (size_t)ca * G::chan_lds);
+                        float2 *s3base = cbase + G::NBUF * G::S2N;
                         int nbt, nr, p0g, lead;
                         span(k, nbt, nr, p0g, lead);
                         const v2f *s2 = reinterpret_cast<const v2f *>(cbase + (k % G::NBUF) * G::S2N) + lead;
@@ -302,7 +312,7 @@ __global__ __launch_bounds__((2 * NC + 2) * kWave) void k_tail_agc(const TailAgc
                 }
             }
         }
-    } else if (wave == 2 * NC) {
+    } else if (wave == NA + NC) {
         // ------------------------------------------------------------------------------------------------------------
         // IF AGC (AGC::adjust), one tile behind the producers; lane = channel
         // ------------------------------------------------------------------------------------------------------------

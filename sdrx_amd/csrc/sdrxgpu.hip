@@ -2409,7 +2409,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         ProfScope ps(b, SDRXGPU_K_TAIL);
         f.gtab = b->d_gtab;
         if (f.n_groups > b->gtab_len) return fail(SDRXGPU_ERR_HIP, "internal: %d groups, index table of %d", f.n_groups, b->gtab_len);
-        hipLaunchKernelGGL(b->ta_kernel, dim3(blocks), dim3((2 * b->ta_nt + 2) * kWave), b->ta_lds + (size_t)((f.n_groups + 3) / 4 * 4) * sizeof(uint32_t),
+        hipLaunchKernelGGL(b->ta_kernel, dim3(blocks), dim3(tail_agc_waves(b->ta_nt) * kWave), b->ta_lds + (size_t)((f.n_groups + 3) / 4 * 4) * sizeof(uint32_t),
                            b->stream, f);
         HIPCHK(hipGetLastError());
         agc_done = true;
