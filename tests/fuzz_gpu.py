@@ -5,7 +5,9 @@ tail, bit for bit; half of the cases also through the device-pointer entry with 
 three channels of every case against the oracle (1e-5); all nine chains, --ftfir on the two 4-stage ones.  Round 2:
 10 355 + 5 487 + 4 193 + 8 387 cases in 240 + 150 + 120 + 200 s on one MI355X (a third of the 10 MS/s cases on the
 fused path), no failure; round 3, final build: 18 567 cases in 420 s (seed 13), no failure.  Round 5: the reference run keeps
-k_tail_s + k_agc, the other takes k_tail_agc where bank_create picks it or is made to (a third of the cases)."""
+k_tail_s + k_agc, the other takes k_tail_agc where bank_create picks it or is made to (a third of the cases); final build (second
+pass of k_tail_agc, compare-free AGC update): 15 904 cases in 420 s (seed 505) + 11 719 in 330 s (seed 909), 12 389 of them through
+k_tail_agc with 1 / 2 / 4 channels per workgroup, no failure."""
 import os
 import random
 import sys
