@@ -151,7 +151,7 @@ typedef struct {
     uint32_t m_seg_groups;   /*   pairs x 16 time segments: (2,2), (4,2) or (2,4); 0 = auto                        */
     uint32_t tail_agc;       /* the remaining decimator stage(s) and the AGC / demodulator as ONE kernel (k_tail_agc: tiles of 32
                                 outputs handed from producer waves to the AGC waves through LDS; same bits as k_tail_s + k_agc):
-                                0 = auto (banks of 256 .. 1 024 channels on the separate tail: 1 to 5 % less time per block; below,
+                                0 = auto (banks of 256 .. 1 024 channels on the separate tail: 3 to 9 % less time per block; below,
                                 the two kernels' own latency chains are shorter than its pipeline's fill, above, its workgroups
                                 no longer fit the chip at once: DESIGN.md 4.10), 1 = never, 2 = require                  */
     uint32_t tail_agc_cpg;   /*   channels per workgroup of that kernel: 1, 2 or 4; 0 = auto                           */
