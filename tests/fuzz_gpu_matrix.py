@@ -5,7 +5,9 @@ stream in one call per block and in a random split must give the same bits; ever
 default one; three channels of every case against the oracle (1e-5), and all of them against the vector kernels (1e-5:
 two summation orders of the same arithmetic, each within its own error of the exact result).  Round 3, final build: 9 215
 cases in 420 s on one MI355X (seed 11; 8 063 more with seed 7), worst 4.5e-6 against the oracle, 5.9e-6 against the vector
-kernels, every split and every workgroup shape bit-identical."""
+kernels, every split and every workgroup shape bit-identical.  Round 5: the scratch stores' streaming cut drawn at random (7 648
+cases, seed 77); a third argument "6" runs the 6 MS/s chain through k_stage12m6 instead: 8 003 cases in 300 s (seed 66), every
+split and lane length bit-identical, worst 4.5e-6 against the oracle, 5.7e-6 against the vector kernels (profiles/r05_m6.txt)."""
 import os
 import random
 import sys
@@ -20,10 +22,11 @@ WHOLE = 0xFFFFFFFF
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 60
 n_cases = 0
-ch = chains.chain("10")
+RATE = sys.argv[3] if len(sys.argv) > 3 else "10"            # "6": k_stage12m6 (bodies of 150 samples, 24 per segment; one workgroup shape)
+ch = chains.chain(RATE)
 L = ch.block_len
 while time.time() < t_end:
-    ftfir = rng.random() < 0.15
+    ftfir = RATE == "10" and rng.random() < 0.15
     n_ch = rng.choice([1, 2, 3, 17, 31, 32, 33, 64, 65, 100, 257, 1023, 1024, 1025, 1500, 2049, 3000])
     kind = rng.choice(["cycled", "random", "mirror", "same"])
     if kind == "cycled":
@@ -38,15 +41,15 @@ while time.time() < t_end:
     tabs = sb.translators_for(ch, offs)
     total = rng.choice([L, L + 12345, 2 * L, L // 2 + 7])
     car = [t for t in tabs[:1] if t is not None]
-    stream = synth.synth_iq(rng.randrange(1 << 30), 0, total, 0.25, car, [0.3] * len(car), ch.N, 10000)
+    stream = synth.synth_iq(rng.randrange(1 << 30), 0, total, 0.25, car, [0.3] * len(car), ch.N, ch.fs // 1000)
     cuts, p = [], 0
     while p < total:
         n = min(total - p, rng.choice([L, L, L // 2, 625, 1, 0, 99999, ch.m_total * 3 + 1]))
         cuts.append(stream[p:p + n]); p += n
     whole = [stream[i:i + L] for i in range(0, total, L)]
     lf = rng.random() < 0.3
-    gs, gt = rng.choice([(0, 0), (2, 2), (4, 2), (2, 4)])
-    hint = rng.choice([0, 0, WHOLE, 1, 2, 3, 4, 6])
+    gs, gt = rng.choice([(0, 0), (2, 2), (4, 2), (2, 4)] if RATE == "10" else [(0, 0), (2, 2)])
+    hint = rng.choice([0, 0, WHOLE, 1, 2, 3, 4, 6] if RATE == "10" else [0, 0, WHOLE, 1, 2, 3, 4, 6, 8, 12])
     keep = rng.choice([0, 1, 1 + rng.randrange(0, 40), 0xFFFFFFFF])      # tuning.y2_keep_mb: which sets' scratch stores stream (same bits)
 
     def run(tuning, hint_, blocks):
