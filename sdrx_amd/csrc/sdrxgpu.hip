@@ -1339,7 +1339,9 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
     // Host parts (sdrxgpu_bank_process copies the rows of part p out while the kernels of part p+1 run): fixed here
     // because the pairing below keeps partners inside one part.  Measured at 10 000 channels, page-locked buffers
     // (ms per block): 1 part 2.26, 2: 1.85, 3: 1.73, 4: 1.68, 5: 1.69, 8: 1.79 (smaller parts fill the chip less well);
-    // automatic: about 2 500 channels per part, at most 4 parts.
+    // automatic: about 2 500 channels per part, at most 4 parts.  (Round 5, tools/lab/time_host_entry.py: 3 parts 1.67, 4: 1.59,
+    // 5: 1.72, 6: 1.79, 8: 1.72; a first part of half / a quarter of the others' size, so that the D2H starts earlier: 1.60 / 1.70
+    // with 4 parts -- the equal parts stay.)
     {
         const int gsz = b->W * b->CPW;
         const int unit = gsz / (int)gcd_ll(gsz, kWave) * kWave;          // whole channel groups and whole k_agc blocks
