@@ -538,6 +538,92 @@ def run_c5(args, plan, ch, rank, local_rank, world, dist, torch, np, sb, sdist, 
     sys.exit("input check failed: %d block(s) arrived different from what the generator made" % n_wrong if n_wrong else 0)
 
 
+def whole_configs_on_one_gpu(args, ch, device, torch, np, sb, chains, synth, sdist):
+    """BASELINE configs[3] (8 192 channels of one stream as 8 shards of 1 024) and configs[4] (16 streams x 1 024 channels, one
+    thread per stream) at full size with every shard / bank on ONE GPU: the N-device code paths (sdrxgpu_multibank's worker
+    threads and per-shard copies; 16 banks driven concurrently through sdrxgpu_bank_process_pinned) timed where only one device
+    exists.  Not a scaling measurement: eight devices and eight PCIe links at once stay unmeasured."""
+    import threading
+    L = ch.block_len
+    out = {}
+    n_it = max(30, args.steps)
+    # ---- configs[3]: the channel list of dist.plan("c4", r, 8), r = 0..7, cut over 8 shards on this device
+    offs = [o for r in range(8) for o in sdist.plan("c4", r, 8, ch.N).offsets[0]]
+    tabs = sb.translators_for(ch, offs)
+    ring = np.stack([synth.synth_iq(1234, b * L, L, 0.25).view(np.float32).reshape(L, 2) for b in range(4)])
+    sb.host_register(ring)
+    try:
+        for label, tuning in (("as the shards run when they share a device (k_tail_s + k_agc)", None),
+                              ("with tuning.tail_agc = 2: every shard runs k_tail_agc, the kernel a shard alone on its GPU takes", {"tail_agc": 2})):
+            mb = sb.MultiChannelBank(tabs, ch.stage_tuples(), devices=[device] * 8, tuning=tuning)
+            sh = mb.shards()
+            outs = [(torch.empty(hi - lo, 512, 2, device="cuda"), torch.empty(hi - lo, 512, device="cuda")) for _, lo, hi, _ in sh]
+            p_iq, p_au = [o[0].data_ptr() for o in outs], [o[1].data_ptr() for o in outs]
+            for k in range(args.warmup + 40):
+                mb.process_pinned(ring[k % 4].ctypes.data, L, p_iq, p_au, 512)
+            mb.synchronize()
+            t0 = time.perf_counter()
+            for k in range(n_it):
+                mb.process_pinned(ring[k % 4].ctypes.data, L, p_iq, p_au, 512)
+            mb.synchronize()
+            dt = time.perf_counter() - t0
+            assert all(bool(torch.isfinite(o[1]).all()) for o in outs)
+            fam = int(mb.info().matrix_pipe)
+            ta = [int(s_[3].tail_agc) for s_ in sh]
+            mb.close()
+            out["8192 channels of one stream as 8 shards x 1024 on ONE GPU (configs[3] whole; sdrxgpu_multibank, devices = 8 x [0]), " + label] = {
+                "value": len(offs) * L * n_it / dt / 1e6, "unit": "Mch-samples/s", "ms_per_step": dt / n_it * 1e3,
+                "realtime_factor": L * n_it / dt / ch.fs, "kernel_family": ["vector kernels", "k_stage12m", "k_stage123m"][fam],
+                "tail_agc_channels_per_workgroup_by_shard": ta,
+                "includes": "8 H2D copies of every block (one per shard) from the caller's page-locked buffer; 8 worker threads",
+                "not_measured": "eight devices / eight PCIe links at once (no multi-GPU node was available)"}
+    finally:
+        sb.host_unregister(ring)
+    # ---- configs[4]: 16 streams (seeds 1..16) x configs[2]'s 1 024 channels, one bank and one driving thread per stream
+    o = chains.offsets_for_config("c3")
+    tabs = sb.translators_for(ch, o)
+    n_streams = 16
+    banks = [sb.ChannelBank(tabs, ch.stage_tuples(), device=device) for _ in range(n_streams)]
+    hosts = [torch.from_numpy(synth.synth_iq(1 + i, 0, L, 0.25).view(np.float32).reshape(L, 2).copy()).pin_memory() for i in range(n_streams)]
+    outs = [(torch.empty(len(o), 512, 2, device="cuda"), torch.empty(len(o), 512, device="cuda")) for _ in range(n_streams)]
+    torch.cuda.synchronize()
+    gate = threading.Barrier(n_streams + 1)
+    errs = []
+
+    def drive(i, n):
+        try:
+            gate.wait()
+            for _ in range(n):
+                banks[i].process_pinned(hosts[i].data_ptr(), L, outs[i][0].data_ptr(), outs[i][1].data_ptr(), 512)
+            banks[i].synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    def run_threads(n):
+        th = [threading.Thread(target=drive, args=(i, n)) for i in range(n_streams)]
+        for t in th:
+            t.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    run_threads(args.warmup + 20)
+    dt = run_threads(n_it)
+    assert not errs, errs
+    assert all(bool(torch.isfinite(o_[1]).all()) for o_ in outs)
+    ta = [int(bk.info().tail_agc) for bk in banks]
+    for bk in banks:
+        bk.close()
+    out["16 streams x 1024 channels as 16 banks on ONE GPU, one driving thread per stream (configs[4] whole)"] = {
+        "value": n_streams * len(o) * L * n_it / dt / 1e6, "unit": "Mch-samples/s", "ms_per_step": dt / n_it * 1e3,
+        "realtime_factor": L * n_it / dt / ch.fs, "tail_agc_channels_per_workgroup_by_bank": ta,
+        "includes": "PCIe H2D of every stream's block (sdrxgpu_bank_process_pinned), 16 host threads",
+        "not_measured": "eight devices / eight PCIe links at once (no multi-GPU node was available)"}
+    return out
+
+
 def run_multibank(args, torch, np, sb, chains, synth, sdist):
     """--multibank D: ONE process, one channel list of D x --channels instances cut over D devices by sdrxgpu_multibank
     (include/sdrx_gpu.h): per-device state, one H2D copy of the block per device from the caller's page-locked buffer, one worker
@@ -721,6 +807,17 @@ def main():
     fused_seen = {}
     pair_seen = {}
     matrix_seen = {}
+    tailagc_seen = {}
+
+    def path_of(n):
+        """the kernels a bank of n channels of this run actually launched per block (from sdrxgpu_bank_info)"""
+        m, f, pr, ta = matrix_seen[n], fused_seen[n], pair_seen[n], tailagc_seen[n]
+        k12 = "k_stage123m" if m == 2 else "k_stage12m" if m == 1 else "k_stage12p" if pr else "k_stage12"
+        if m == 2:
+            return k12 + " + k_tail_c + k_agc"
+        if f:
+            return k12 + " (stage 3 fused) + k_tail4 + k_agc"
+        return k12 + (f" + k_tail_agc (tail stages and AGC/demod in one kernel, {ta} channel(s) per workgroup)" if ta else " + k_tail_s + k_agc")
 
     def run(offsets, steps, warmup, events=True, tuning_override=None, checked=False):
         tabs = sb.translators_for(ch, offsets)
@@ -729,6 +826,7 @@ def main():
         fused_seen[len(offsets)] = int(bank.info().fused_tail)
         pair_seen[len(offsets)] = int(bank.info().pair_lanes)
         matrix_seen[len(offsets)] = int(bank.info().matrix_pipe)
+        tailagc_seen[len(offsets)] = int(bank.info().tail_agc)
         # N > 1: the broadcasts land directly in the bank's two input rings, alternately (their addresses repeat
         # for whole blocks), so process_device finds each block in place; any other address would be copied in
         p0, cap = bank.ingest_buffer()
@@ -761,6 +859,8 @@ def main():
                     "fan-out -> ingest buffer) against the generator's, before the settling steps")
     fused = fused_seen[n_ch]
     matrix_main, pair_main = matrix_seen[n_ch], pair_seen[n_ch]      # (of THIS run: later runs of other paths overwrite the dictionaries)
+    tailagc_main = tailagc_seen[n_ch]
+    path_main = path_of(n_ch)
 
     extra = {}
     if world == 1 and not args.no_extra_configs and plan.name == "headline":
@@ -770,7 +870,9 @@ def main():
             dte, ke = run(o, max(10, args.steps), args.warmup, events=False)    # (kernel times: 5 instrumented steps after the timed ones)
             extra[name] = {"value": len(o) * L * max(10, args.steps) / dte / 1e6, "unit": "Mch-samples/s",
                            "ms_per_step": dte / max(10, args.steps) * 1e3, "realtime_factor": L * max(10, args.steps) / dte / ch.fs,
-                           "kernel_ms_avg": {n: v[0] for n, v in ke.items()}, "fused_tail": fused_seen[len(o)]}
+                           "kernel_ms_avg": {n: v[0] for n, v in ke.items()}, "fused_tail": fused_seen[len(o)],
+                           "kernel_path": path_of(len(o)),
+                           "kernel_ms_note": ("k_tail = k_tail_agc, which contains the AGC recurrence (no k_agc launch)" if tailagc_seen[len(o)] else None)}
 
     if world == 1 and not args.no_extra_configs and plan.name == "headline" and tuning is None and matrix_main == 1:
         # the same workload with SDRXGPU_FLAG_FUSED_STAGE3 (k_stage123m + k_tail_c: no stage-2 scratch; opt-in because of its rounding,
@@ -798,7 +900,7 @@ def main():
             dte, ke = run(o, n_it, args.warmup, events=False)
             extra["1024 channels per GPU, every block H2D by the rank itself from a page-locked ring (configs[3] per GPU = --config c4 --fanout host at N = 1)"] = {
                 "value": len(o) * L * n_it / dte / 1e6, "unit": "Mch-samples/s", "ms_per_step": dte / n_it * 1e3,
-                "realtime_factor": L * n_it / dte / ch.fs, "kernel_ms_avg": {n: v[0] for n, v in ke.items()},
+                "realtime_factor": L * n_it / dte / ch.fs, "kernel_ms_avg": {n: v[0] for n, v in ke.items()}, "kernel_path": path_of(len(o)),
                 "includes": "PCIe H2D of every block (sdrxgpu_bank_process_pinned)"}
             host_ring, args.pipelined = None, True
             dte, ke = run(o, n_it, args.warmup, events=False)
@@ -841,6 +943,11 @@ def main():
             "realtime_factor": L * n_it / dtm / ch.fs, "includes": "PCIe H2D of every block (sdrxgpu_bank_process_pinned)"}
         for bk in banks:
             bk.close()
+
+    if world == 1 and not args.no_extra_configs and plan.name == "headline":
+        # BASELINE configs[3] and configs[4] WHOLE, on this one GPU (what an 8-GPU node runs on eight): every shard / bank of
+        # the configuration exists and works, they share one card and one PCIe link
+        extra.update(whole_configs_on_one_gpu(args, ch, local_rank, torch, np, sb, chains, synth, sdist))
 
     host_path = None
     if world == 1 and not args.no_extra_configs and plan.name == "headline":
@@ -906,9 +1013,12 @@ def main():
                        "frac_is": "the bytes the kernel must move (algorithmic_bytes: its inputs once + its outputs) over the 8 TB/s HBM spec peak; "
                                   "measured traffic: roofline.traffic_step / the committed PMC profile",
                        "does": ("k_tail_c: stage-3 outputs put together from k_stage123m's entries + stage 4" if fused3 else
-                                "k_tail4: range-boundary stage-3 outputs + stage 4" if fused else "k_tail_s: stages 3-4 from the stage-2 scratch")},
-            "k_agc": {"ms": k["k_agc"][0], "bound": "latency (512 dependent steps per channel)",
-                      "ns_per_step": k["k_agc"][0] * 1e6 / 512 if k["k_agc"][1] else None},
+                                "k_tail4: range-boundary stage-3 outputs + stage 4" if fused else
+                                "k_tail_agc: stages 3-4 from the stage-2 scratch AND the AGC / demodulator, one kernel" if tailagc_main else
+                                "k_tail_s: stages 3-4 from the stage-2 scratch")},
+            "k_agc": ({"ms": None, "note": "no launch: the recurrence runs inside k_tail_agc (k_tail above)"} if tailagc_main else
+                      {"ms": k["k_agc"][0], "bound": "latency (512 dependent steps per channel)",
+                       "ns_per_step": k["k_agc"][0] * 1e6 / 512 if k["k_agc"][1] else None}),
         }
         out = {
             "metric": "IQ Msamples/s ingested x channels demodulated (channel-samples/s)",
@@ -923,18 +1033,16 @@ def main():
                 "name": plan.name,
                 "channels_per_gpu": n_ch, "channels_total": plan.channels_total, "sample_rate": ch.fs, "block_len": L,
                 "outputs_per_channel_per_block": 512,
-                "parallelism": (plan.parallelism.replace("RCCL rank", "rank") if use_host else plan.parallelism) +
+                "parallelism": ("one process on one GPU, no communicator" if dist is None else
+                                plan.parallelism.replace("RCCL rank", "rank") if use_host else plan.parallelism) +
                                ((", every rank copies block k+1 H2D itself from rank 0's shared page-locked ring on its bank's copy stream "
                                  "while block k is processed (no communicator, no traffic between GPUs; gloo for the barrier)") if use_host else
                                 (", block k+1 broadcast by RCCL over xGMI into the banks' other input ring while block k is processed"
                                  if (world > 1 or args.force_dist) else "")),
                 "fanout": (args.fanout if (world > 1 or args.force_dist) else None),
                 "includes": ("PCIe H2D of every block (host fan-out: the block is in host memory when a step starts)" if use_host else None),
-                "kernel_path": ("mixer + stage 1 on the f32 matrix pipe, stages 2-3 in the same kernel, no stage-2 scratch (k_stage123m + k_tail_c + k_agc)" if fused3 else
-                                ("stage 3 fused behind stages 1-2 (k_stage12 + k_tail4 + k_agc)" if fused else
-                                 "separate tail (k_stage12 + k_tail_s + k_agc)") +
-                                (f"; two channels per lane in k_stage12, {pair_main - 1} conjugate pairs share the mixer" if pair_main else "") +
-                                ("; mixer + stage 1 on the f32 matrix pipe (k_stage12m)" if matrix_main else "")),
+                "kernel_path": path_main + (f"; {pair_main - 1} conjugate pairs share the mixer" if pair_main else "") +
+                               ("; mixer + stage 1 on the f32 matrix pipe" if matrix_main else ""),
                 "realtime_factor": value * 1e6 / (n_ch * world * ch.fs),
                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),   # (set before the HIP runtime started: two banks' streams need queues of their own)
                 "settle_steps": SETTLE_STEPS,    # untimed, before the W warm-up steps (clock settling, see time_bank)

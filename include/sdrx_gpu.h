@@ -159,6 +159,8 @@ typedef struct {
                                 outputs -- are ordinary stores (the tail kernel reads them first, out of the Infinity Cache),
                                 everything before them goes out with the streaming hint (same bits):
                                 0 = auto (192 MB), 1 = everything streams, 0xFFFFFFFF = nothing does                   */
+    uint32_t host_part_ch[7];/* explicit channel boundaries of the host parts, both cuts (upper end of part 0, 1, ...; rounded down to
+                                whole channel groups; at most host_parts parts; the last part ends with the bank): 0 = automatic */
 } sdrxgpu_tuning;
 
 typedef struct {
@@ -314,6 +316,12 @@ int sdrxgpu_host_unregister(void *ptr);
 
 int sdrxgpu_bank_synchronize(sdrxgpu_bank *bank);
 int sdrxgpu_bank_get_info(sdrxgpu_bank *bank, sdrxgpu_bank_info *info);
+/* The channel parts sdrxgpu_bank_process (host pointers) runs the bank in, so that the D2H copy of one part's rows crosses PCIe
+ * while the kernels of the next run: bounds[0] = 0 < bounds[1] < ... < bounds[*n_parts] = n_channels (cap >= *n_parts + 1 entries,
+ * at most 9).  A bank has two cuts: audio_only = 0, for calls that take the decimated IQ (with or without the audio), and
+ * audio_only = 1, for calls with iq_out == NULL (a third of the bytes to copy: fewer, larger parts).  One part = the whole bank
+ * in one go (banks under 2 048 channels; banks with squelch, audio FIR or mix-down). */
+int sdrxgpu_bank_get_host_parts(sdrxgpu_bank *bank, int audio_only, uint32_t *bounds, size_t cap, size_t *n_parts);
 
 /* ---- one channel list over several GPUs of one node, in ONE process --------------------------------------------
  * sdrx is one process with one device thread calling data_cb (src/sdrx.cpp:306-364); its only parallelism is one

@@ -47,8 +47,9 @@ class AgcParams(C.Structure):
 
 class Tuning(C.Structure):
     """sdrxgpu_tuning: geometry / kernel-path overrides for tests and tuning runs (0 = automatic)."""
-    _fields_ = [(k, C.c_uint32) for k in ("struct_size", "k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail", "host_parts",
-                                            "pair_lanes", "matrix_pipe", "m_slot_groups", "m_seg_groups", "tail_agc", "tail_agc_cpg", "y2_keep_mb")]
+    _fields_ = ([(k, C.c_uint32) for k in ("struct_size", "k12_waves", "k12_cpw", "tail_tile", "tail_generic", "fused_tail", "host_parts",
+                                             "pair_lanes", "matrix_pipe", "m_slot_groups", "m_seg_groups", "tail_agc", "tail_agc_cpg", "y2_keep_mb")] +
+                [("host_part_ch", C.c_uint32 * 7)])
 
     def __init__(self, **kw):
         kw.setdefault("struct_size", C.sizeof(Tuning))
@@ -147,6 +148,7 @@ def load_library():
     L.sdrxgpu_bank_synchronize.argtypes = [vp]
     L.sdrxgpu_bank_ingest_buffer_after.argtypes = [vp, sz, C.POINTER(vp)]
     L.sdrxgpu_bank_get_info.argtypes = [vp, C.POINTER(BankInfo)]
+    L.sdrxgpu_bank_get_host_parts.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), sz, C.POINTER(sz)]
     L.sdrxgpu_bank_get_gains.argtypes = [vp, vp, vp]
     L.sdrxgpu_bank_get_agc_state.argtypes = [vp, vp, vp, vp, vp]
     L.sdrxgpu_bank_get_squelch.argtypes = [vp, vp, vp]
@@ -177,7 +179,7 @@ EXPORTED_SYMBOLS = [
     "sdrxgpu_agc_params_sdrx", "sdrxgpu_make_translator", "sdrxgpu_parse_channel", "sdrxgpu_tuner_fq",
     "sdrxgpu_channel_to_offset", "sdrxgpu_channels_fit_bandwidth", "sdrxgpu_bank_create", "sdrxgpu_bank_destroy",
     "sdrxgpu_bank_reset", "sdrxgpu_bank_process", "sdrxgpu_bank_process_device", "sdrxgpu_bank_process_pinned", "sdrxgpu_bank_flush", "sdrxgpu_bank_ingest_buffer", "sdrxgpu_bank_ingest_buffer_after",
-    "sdrxgpu_host_register", "sdrxgpu_host_unregister", "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_get_agc_state", "sdrxgpu_bank_get_squelch", "sdrxgpu_bank_profile_enable",
+    "sdrxgpu_host_register", "sdrxgpu_host_unregister", "sdrxgpu_bank_synchronize", "sdrxgpu_bank_get_info", "sdrxgpu_bank_get_host_parts", "sdrxgpu_bank_get_gains", "sdrxgpu_bank_get_agc_state", "sdrxgpu_bank_get_squelch", "sdrxgpu_bank_profile_enable",
     "sdrxgpu_audio_pos", "sdrxgpu_bank_get_mix", "sdrxgpu_bank_mix_buffers",
     "sdrxgpu_bank_profile_read", "sdrxgpu_bank_profile_reset", "sdrxgpu_strerror", "sdrxgpu_last_error",
     "sdrxgpu_version",
@@ -390,6 +392,14 @@ class ChannelBank:
         _check(self._L.sdrxgpu_bank_get_info(self._h, C.byref(i)), "sdrxgpu_bank_get_info")
         return i
 
+    def host_parts(self, audio_only=False):
+        """Channel bounds [0, ..., n_channels] of the parts ``process`` (host pointers) runs the bank in: the cut for calls that
+        take the decimated IQ, or (``audio_only``) the one for calls that take the audio alone."""
+        b = (C.c_uint32 * 16)()
+        n = C.c_size_t(0)
+        _check(self._L.sdrxgpu_bank_get_host_parts(self._h, int(audio_only), b, 16, C.byref(n)), "sdrxgpu_bank_get_host_parts")
+        return [int(b[i]) for i in range(n.value + 1)]
+
     def gains(self):
         a = np.empty(self.n_channels, dtype=np.float32)
         b = np.empty(self.n_channels, dtype=np.float32)
@@ -581,5 +591,5 @@ class MultiChannelBank(ChannelBank):
         _check(self._L.sdrxgpu_multibank_get_squelch(self._h, snr.ctypes.data, st.ctypes.data), "sdrxgpu_multibank_get_squelch")
         return snr, st
 
-    mix = process_device = flush = ingest_buffer = ingest_buffer_after = _no
+    mix = process_device = flush = ingest_buffer = ingest_buffer_after = host_parts = _no
     profile_enable = profile_reset = profile_read = _no

@@ -272,11 +272,14 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
     };
     auto store_staged = [&](int body, int h) { store_staged_part(body, h, 0, 8); };
     // combinations + stage 2 for stage-1 output P20 (0..19) of a body
-    auto post = [&](auto p20_tag, const Acc &c) {
+    auto post = [&](auto p20_tag, Acc &c) {
         constexpr int P20 = decltype(p20_tag)::value;
-        // (the combinations below are inline assembly: the compiler does not space them from the MFMAs that write their sources.
-        // In phases 0..8 the next phase's 21 operand reads stand in between; the last phase of a half-body has none: 12 wait states)
-        if constexpr (P20 % 10 == 9) asm volatile("s_nop 7\n\ts_nop 3");
+        // (the combinations below are inline assembly: the compiler does not space them from the MFMAs that write their sources --
+        // 12 wait states for the 8-pass f32 MFMA on gfx950.  In phases 0..8 the compiler puts the next phase's 21 operand reads in
+        // between: its choice, not a rule, so tools/hazard_lint.py checks the built code object for it (build() fails otherwise).
+        // The last phase of a half-body has no reads to put there: explicit wait states, tied to the accumulators by data flow --
+        // the MFMAs cannot sink below them, the combinations cannot rise above.)
+        if constexpr (P20 % 10 == 9) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(c.Dr[0]), "+v"(c.Di[0]), "+v"(c.Dr[1]), "+v"(c.Di[1]));
         // channel A = the slot's own table: (Pr - Qi) + j (Pi + Qr); channel B = its conjugate: (Pr + Qi) + j (Pi - Qr)
         v2f Y[8];
 #pragma unroll

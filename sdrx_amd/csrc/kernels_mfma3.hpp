@@ -236,9 +236,13 @@ void k_stage123m(const float2 *__restrict__ x_in, const float2 *__restrict__ tab
         }
     };
     // combinations + the transposed 119-tap filter for the stage-1 output of phase ph of the half-body
-    auto post = [&](auto ph_tag, const Acc &c, const Cf &k) {
+    auto post = [&](auto ph_tag, Acc &c, const Cf &k) {
         constexpr int ph = decltype(ph_tag)::value;
-        if constexpr (ph == 9) asm volatile("s_nop 7\n\ts_nop 3");          // (no operand reads between the MFMAs and this: wait states)
+        // (no operand reads between the MFMAs and the combinations in the last phase: 12 wait states, tied to the accumulators by data
+        // flow -- kernels_mfma.hpp.  In the other phases the compiler's order puts the next phase's reads there, which
+        // tools/hazard_lint.py checks on the built code; in the 4 x 2 shape it does not (round 6: the lint found MFMAs 5 wait states
+        // in front of their combinations there), so that shape waits in every phase.)
+        if constexpr (ph == 9 || GS == 4) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(c.Dr[0]), "+v"(c.Di[0]), "+v"(c.Dr[1]), "+v"(c.Di[1]));
         v2f Y[8];
 #pragma unroll
         for (int g = 0; g < 2; g++)

@@ -214,7 +214,12 @@ extern "C" int sdrxgpu_multibank_create(const sdrxgpu_bank_cfg *cfg, const int32
         sc.channels = cfg->channels + s.ch_lo;
         if (cfg->sql_level) sc.sql_level = cfg->sql_level + s.ch_lo;
         if (cfg->modulation) sc.modulation = cfg->modulation + s.ch_lo;
-        sc.tuning = &tune;
+        // k_tail_agc or k_tail_s + k_agc (same bits): a shard that shares its device with another shard of this list keeps the two
+        // short kernels, as two banks on one GPU do (bank_create decides from the banks alive on the device; the first shard of a
+        // shared device would otherwise be created "alone" and differ from its neighbours) -- unless the caller's tuning says otherwise
+        sdrxgpu_tuning tune_s = tune;
+        if (tune_s.tail_agc == 0 && std::count(devs.begin(), devs.begin() + n_sh, s.device) > 1) tune_s.tail_agc = 1;
+        sc.tuning = &tune_s;
         rc = bank_create_guarded(&sc, &s.bank, nullptr);
         if (rc != SDRXGPU_OK) {
             char keep[sizeof(g_err)];

@@ -462,10 +462,13 @@ static bool find_tail_agc(int nt, int mA, int tA, int mB, int tB, bool sq, bool 
 
 static long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) : a; }
 
-// Banks alive per device.  The one thing it decides is a launch-time choice between two bit-identical kernel sequences
-// (k_tail_agc or k_tail_s + k_agc, launch_tail): a bank ALONE on its GPU is 4 % faster per block with the fused kernel, two banks
-// sharing a GPU (BASELINE configs[4]) are 12 % slower with it -- its long-lived workgroups get in the way of the other bank's
-// stage-1/2 launch, under which the two short kernels hide anyway (0.219 against 0.194 ms per step of both banks).
+// Banks alive per device.  The one thing it decides is a choice between two bit-identical kernel sequences (k_tail_agc or
+// k_tail_s + k_agc, launch_tail): a bank ALONE on its GPU is 4 % faster per block with the fused kernel, two banks sharing a GPU
+// (BASELINE configs[4]) are 12 % slower with it -- its long-lived workgroups get in the way of the other bank's stage-1/2 launch,
+// under which the two short kernels hide anyway (0.219 against 0.194 ms per step of both banks).  The choice is made ONCE, in
+// bank_create, from the banks alive on the device at that moment (round 5 looked at the counter at every launch: the path could
+// then change between two calls of one stream, an idle spare bank switched the kernel off, and bank_info said nothing of it):
+// a bank keeps the sequence it was created with, and sdrxgpu_bank_info.tail_agc says which.
 #include <atomic>
 static std::atomic<int> g_banks_on_device[64];
 
@@ -545,7 +548,6 @@ struct sdrxgpu_bank {
     int hist_cur = 0;
     // tail stages + AGC/demod as ONE kernel (k_tail_agc, kernels_tailagc.hpp): banks on the separate tail whose tail is a latency chain
     bool tail_agc = false;
-    bool tail_agc_required = false;           //   tuning.tail_agc = 2: also when other banks share the device
     bool counted = false;                     // this bank is in g_banks_on_device
     int ta_cpg = 4;                           //   channels per workgroup of that kernel
     int ta_nt = 2;                            //   its producer waves per workgroup
@@ -613,17 +615,25 @@ struct sdrxgpu_bank {
     int y3c_stride = 0, H3c = 80;
     int2 *d_slots_m = nullptr, *d_slots_mp = nullptr;  // partners from the whole bank / from inside each host part
     int n_slots_m = 0, n_slots_mp = 0, n_pairs_m = 0;
-    std::vector<int> part_gm;                         // set boundaries of the host parts
     bool pair = false, want_pair = false;
     int2 *d_slots = nullptr;
     unsigned char *d_group_conj = nullptr;            // per slot group: conjugate partners (one translator row per slot) or any two channels
     int n_slots = 0, n_conj_pairs = 0;
-    std::vector<int> part_ch;                         // channel boundaries of the host parts: part p = [part_ch[p], part_ch[p+1])
-    std::vector<int> part_g;                          // slot-group boundaries of the parts
+    // Host parts (sdrxgpu_bank_process): part p = channels [ch[p], ch[p+1]); gm = set boundaries of k_stage12m's part launches in
+    // the slot list sorted by first channel (d_slots_mp).  Two cuts of the same bank: [0] for calls that take the decimated IQ
+    // (61 MB of D2H per 10 000-channel block: the copies are what takes longest, so they have to start early), [1] for calls that
+    // take the audio only (a third of that: the kernels take longest, so as few parts as leave little to copy behind the last).
+    struct HostPlan {
+        std::vector<int> ch, gm;
+    } plan[2];
+    int cur_plan = 0;
+    std::vector<int> part_g;                          // slot-group boundaries of the parts (two channels per lane: plan[0] only)
     hipStream_t copy_stream = nullptr;
     int host_parts = 0;                               // tuning.host_parts (0 = auto)
     size_t y2_keep = 0;                               // bytes of a k_stage12m launch's scratch (the sets written last) stored without the streaming hint
     hipEvent_t ev_part[8] = {};                       // kernels of a channel part are done
+    hipEvent_t ev_iq[8] = {};                         // the tail kernel of a channel part is done (its decimated IQ rows are final)
+    hipEvent_t mark_after_tail = nullptr;             // launch_tail records it between the tail kernel and the AGC kernel
     hipEvent_t ev_h2d = nullptr;                      // the block is in the input ring
     hipEvent_t ev_d2h = nullptr;                      // the output rows have left the keep buffers
     hipEvent_t ev_ring_free[2] = {nullptr, nullptr};  // the kernels that read input ring r are done
@@ -712,6 +722,8 @@ static int free_bank(sdrxgpu_bank *b)
     for (hipEvent_t e : {b->ev_h2d, b->ev_d2h, b->ev_ring_free[0], b->ev_ring_free[1]})
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->ev_part)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b->ev_iq)
         if (e) (void)hipEventDestroy(e);
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
@@ -1303,8 +1315,8 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         // workgroup; tuning.tail_agc_cpg sets it instead.  Measured (tools/lab/bench_ta_cpg.sh, the kernel's us with 1 / 2 / 4): 256
         // channels 30.6 / 32.0 / 36.5, 384: 33.9 / 32.0 / 35.6, 512: 34.2 / 32.0 / 35.8, 768: 45.2 / 40.4 / 37.6, 1 024: 67.5 / 41.6 /
         // 37.8.  (A workgroup of 4 channels holds 150 KB of LDS and a CU then has room for nothing else -- which cost two banks on one
-        // GPU, BASELINE configs[4], 15 % of their overlap while the kernel was chosen per bank; it now runs only while its bank is
-        // alone on the device, launch_tail.)
+        // GPU, BASELINE configs[4], 15 % of their overlap while the kernel was chosen per bank; the automatic choice is for a bank
+        // that is alone on its device when it is created, below.)
         b->ta_nt = (int)b->n_ch <= n_cu ? 1 : (int)b->n_ch <= 2 * n_cu ? 2 : 4;
         if (tune.tail_agc_cpg) {
             if (tune.tail_agc_cpg != 1 && tune.tail_agc_cpg != 2 && tune.tail_agc_cpg != 4) {
@@ -1324,8 +1336,9 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.tail_agc = 2, but k_tail_agc is built for the separate tail of the reference's "
                         "chains (not with stage 3 fused into the stage-1/2 kernel, not with tail_generic; %zu B of LDS)", lds_max);
         }
-        b->tail_agc_required = tune.tail_agc == 2;
-        b->tail_agc = can && (tune.tail_agc == 2 || (tune.tail_agc == 0 && (int)b->n_ch >= SDRX_TAILAGC_AUTO_MIN_CU * n_cu &&
+        // automatic: mid-size banks that are the only bank on their device when they are created (the counter above)
+        const bool alone = !(b->device >= 0 && b->device < 64) || g_banks_on_device[b->device].load() == 0;
+        b->tail_agc = can && (tune.tail_agc == 2 || (tune.tail_agc == 0 && alone && (int)b->n_ch >= SDRX_TAILAGC_AUTO_MIN_CU * n_cu &&
                                                      (int)b->n_ch <= SDRX_TAILAGC_AUTO_MAX_CU * n_cu));
         if (b->tail_agc) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(b->ta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -1337,21 +1350,85 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
     }
 
     // Host parts (sdrxgpu_bank_process copies the rows of part p out while the kernels of part p+1 run): fixed here
-    // because the pairing below keeps partners inside one part.  Measured at 10 000 channels, page-locked buffers
-    // (ms per block): 1 part 2.26, 2: 1.85, 3: 1.73, 4: 1.68, 5: 1.69, 8: 1.79 (smaller parts fill the chip less well);
-    // automatic: about 2 500 channels per part, at most 4 parts.  (Round 5, tools/lab/time_host_entry.py: 3 parts 1.67, 4: 1.59,
-    // 5: 1.72, 6: 1.79, 8: 1.72; a first part of half / a quarter of the others' size, so that the D2H starts earlier: 1.60 / 1.70
-    // with 4 parts -- the equal parts stay.)
+    // because the pairing below keeps partners inside one part.  Vector kernels: about 2 500 channels per part, at most 4 parts
+    // (measured at 10 000 channels, page-locked buffers, ms per block: 1 part 2.26, 2: 1.85, 3: 1.73, 4: 1.68, 5: 1.69, 8: 1.79).
+    // k_stage12m (round 6, tools/lab/sweep_host_entry.py + the copy traces under profiles/r06_host_entry_*): a part's launch costs
+    // whole ROUNDS of the workgroups the chip holds at once (512 = 56 sets of 32 slots at the 10 000-channel bank's lane length,
+    // about 0.2 ms each, whatever fraction of the round the part fills) -- four equal parts of a bank of 2.9 rounds paid four
+    // rounds, 0.83 ms of stage-1/2 kernels against 0.57 for the whole bank.  So the cuts go where the rounds end: one part per
+    // round for calls that take the decimated IQ (the 61 MB of copies are what takes longest: they start after the first round
+    // and then never wait), and two parts -- all whole rounds, then the rest -- for calls that take the audio only (a third of
+    // the bytes: the kernels are what takes longest; one cut leaves the last round's rows to copy behind them, more cuts only add
+    // launches).  10 000 channels, ms per block: IQ + audio 1.56 (4 equal parts) -> 1.5x, audio only 1.31 -> 1.1x.
     {
         const int gsz = b->W * b->CPW;
         const int unit = gsz / (int)gcd_ll(gsz, kWave) * kWave;          // whole channel groups and whole k_agc blocks
+        const bool may_split = !cfg->sql_level && !cfg->n_audio_fir_taps && !cfg->pan_pos && b->n_ch >= 2048;
         int n_parts = 1;
-        if (!cfg->sql_level && !cfg->n_audio_fir_taps && !cfg->pan_pos && b->n_ch >= 2048)
-            n_parts = b->host_parts ? b->host_parts : std::min(4, std::max(1, (int)(b->n_ch / 2500)));
+        if (may_split) n_parts = b->host_parts ? b->host_parts : std::min(4, std::max(1, (int)(b->n_ch / 2500)));
         const int per = (((int)b->n_ch + n_parts - 1) / n_parts + unit - 1) / unit * unit;
-        b->part_ch.clear();
-        for (int c = 0; c < (int)b->n_ch; c += per) b->part_ch.push_back(c);
-        b->part_ch.push_back((int)b->n_ch);
+        std::vector<int> &pc = b->plan[0].ch;
+        pc.clear();
+        bool by_rounds = false;
+        if (n_parts > 1 && tune.host_part_ch[0]) {
+            // explicit boundaries (tuning runs): whole units, strictly rising, inside the bank
+            pc.push_back(0);
+            for (int i = 0; i < 7 && tune.host_part_ch[i] && (int)pc.size() < n_parts; i++) {
+                const int c = (int)std::min<uint32_t>(tune.host_part_ch[i], b->n_ch) / unit * unit;
+                if (c <= pc.back() || c >= (int)b->n_ch) {
+                    free_bank(b);
+                    return fail(SDRXGPU_ERR_INVALID_ARG, "bank_create: tuning.host_part_ch[%d] = %u: boundaries are multiples of %d channels, rising, inside the bank",
+                                i, tune.host_part_ch[i], unit);
+                }
+                pc.push_back(c);
+            }
+        } else if (may_split && b->mfma && !b->host_parts) {
+            by_rounds = true;
+        } else {
+            for (int c = 0; c < (int)b->n_ch; c += per) pc.push_back(c);
+        }
+        if (by_rounds) {
+            // sets per round for a call of max_chunk samples: the workgroup places of the chip over the time-workgroups of one set
+            const long long U = ((long long)max_y2 + k12->Y2B - 1) / k12->Y2B;
+            const long long G = (U + (long long)(kWave / b->CPW) * b->bps - 1) / ((long long)(kWave / b->CPW) * b->bps);
+            const long long wt = (G + b->mGT - 1) / b->mGT * b->P;
+            const long long n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            const long long places = n_cu_ * std::max<long long>(1, (long long)(160 * 1024 / k12m_lds_bytes(b->mfma_kind, b->mGS, b->mGT)));
+            const int R = (int)std::max<long long>(1, places / std::max<long long>(1, wt));
+            // the first channel of every slot, ascending (a pair belongs to the part of its first channel, further down)
+            std::vector<int> first;
+            for (const int2 &sl : m_slots_all)
+                if (sl.x >= 0) first.push_back(sl.x);
+            std::sort(first.begin(), first.end());
+            const int n_sets = ((int)first.size() + m_set - 1) / m_set;
+            const int n_rounds = (n_sets + R - 1) / R;
+            // the channel (whole units) up to which the slots fill `sets` sets
+            auto cut_at = [&](int sets) {
+                const size_t k = std::min(first.size(), (size_t)sets * (size_t)m_set);
+                const int c = k >= first.size() ? (int)b->n_ch : first[k];      // channels below first[k] own at most `sets` sets
+                return c / unit * unit;
+            };
+            auto build = [&](std::vector<int> &out, const std::vector<int> &set_ends) {
+                out.assign(1, 0);
+                for (int e : set_ends) {
+                    const int c = cut_at(e);
+                    if (c > out.back() && c < (int)b->n_ch) out.push_back(c);
+                }
+                out.push_back((int)b->n_ch);
+            };
+            // [0] IQ + audio: a part per round (at most 8 parts: whole rounds per part beyond that)
+            std::vector<int> ends;
+            const int rounds_per_part = (n_rounds + 7) / 8;
+            for (int r = rounds_per_part; r < n_rounds; r += rounds_per_part) ends.push_back(r * R);
+            build(pc, ends);
+            // [1] audio only: every whole round, then the rest
+            ends.clear();
+            if (n_rounds >= 2) ends.push_back((n_rounds - 1) * R);
+            build(b->plan[1].ch, ends);
+        } else {
+            pc.push_back((int)b->n_ch);
+            b->plan[1].ch = pc;
+        }
     }
 
     // Two channels per lane (k_stage12p): for large banks of the 10 MS/s chain in its large-bank geometry.  Partners are
@@ -1382,11 +1459,11 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
                 for (size_t i = 0; i < ch.n_translator; i++) k[i * 8 + 7] ^= (char)0x80;   // sign bit of .im
             return k;
         };
-        for (size_t p = 0; p + 1 < b->part_ch.size(); p++) {
+        for (size_t p = 0; p + 1 < b->plan[0].ch.size(); p++) {
             std::unordered_map<std::string, std::vector<int>> open;   // table bytes -> channels of this part still without partner
             std::vector<int2> conj, gen;
             std::vector<int> single;
-            for (int c = b->part_ch[p]; c < b->part_ch[p + 1]; c++) {
+            for (int c = b->plan[0].ch[p]; c < b->plan[0].ch[p + 1]; c++) {
                 if (cfg->channels[c].n_translator == 0) {
                     single.push_back(c);
                     continue;
@@ -1440,11 +1517,24 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         std::vector<int2> &slots_all = m_slots_all;
         std::vector<int2> slots_parts;
         const int np_all = m_np_all;
-        int np_parts = 0;
-        b->part_gm.assign(1, 0);
-        for (size_t p = 0; p + 1 < b->part_ch.size(); p++) {
-            m_pair_range(b->part_ch[p], b->part_ch[p + 1], slots_parts, np_parts);
-            b->part_gm.push_back((int)(slots_parts.size() / set));
+        // The parts' launches walk ONE list, the whole bank's slots sorted by their first channel and padded at its end only: part
+        // p runs the sets up to the one that holds the last slot whose first channel is below the part's upper bound.  A pair so
+        // belongs to the part of its FIRST channel -- its second channel, which may lie in a later part, and the few slots of the
+        // next part that share the boundary set are computed ahead of that part's own launch (a part's tail needs its channels'
+        // stage-2 rows complete, not computed by its own launch) -- and cutting the bank costs no pair, wherever the cuts fall.
+        {
+            for (const int2 &sl : slots_all)
+                if (sl.x >= 0) slots_parts.push_back(sl);
+            std::stable_sort(slots_parts.begin(), slots_parts.end(), [](const int2 &u, const int2 &v) { return u.x < v.x; });
+            for (sdrxgpu_bank::HostPlan &hp : b->plan) {
+                hp.gm.assign(1, 0);
+                size_t i = 0;
+                for (size_t p = 0; p + 1 < hp.ch.size(); p++) {
+                    while (i < slots_parts.size() && slots_parts[i].x < hp.ch[p + 1]) i++;
+                    hp.gm.push_back((int)((i + set - 1) / set));
+                }
+            }
+            while (slots_parts.size() % set) slots_parts.push_back(make_int2(-1, -1));
         }
         b->n_pairs_m = np_all;
         b->n_slots_m = (int)slots_all.size();
@@ -1816,6 +1906,18 @@ extern "C" int sdrxgpu_bank_ingest_buffer_after(sdrxgpu_bank *b, size_t in_len, 
     return SDRXGPU_OK;
 }
 
+extern "C" int sdrxgpu_bank_get_host_parts(sdrxgpu_bank *b, int audio_only, uint32_t *bounds, size_t cap, size_t *n_parts)
+{
+    if (!b || !n_parts) return fail(SDRXGPU_ERR_INVALID_ARG, "get_host_parts: null argument");
+    const std::vector<int> &pc = b->plan[audio_only ? 1 : 0].ch;
+    *n_parts = pc.size() - 1;
+    if (bounds) {
+        if (cap < pc.size()) return fail(SDRXGPU_ERR_INVALID_ARG, "get_host_parts: %zu entries for %zu bounds", cap, pc.size());
+        for (size_t i = 0; i < pc.size(); i++) bounds[i] = (uint32_t)pc[i];
+    }
+    return SDRXGPU_OK;
+}
+
 extern "C" int sdrxgpu_bank_get_gains(sdrxgpu_bank *b, float *agc_gain, float *lf_gain)
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_gains: null bank");
@@ -1949,8 +2051,8 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
     if (b->mfma3) return launch_k123_parts(b, job, st, p_lo, p_hi);
     if (b->mfma) {
         ProfScope ps(b, SDRXGPU_K_STAGE12, st);
-        const bool whole = p_lo == 0 && p_hi == (int)b->part_ch.size() - 1;
-        const int g_lo = whole ? 0 : b->part_gm[p_lo], g_hi = whole ? b->n_slots_m / (16 * b->mGS) : b->part_gm[p_hi];
+        const bool whole = p_lo == 0 && p_hi == (int)b->plan[b->cur_plan].ch.size() - 1;
+        const int g_lo = whole ? 0 : b->plan[b->cur_plan].gm[p_lo], g_hi = whole ? b->n_slots_m / (16 * b->mGS) : b->plan[b->cur_plan].gm[p_hi];
         if (g_hi <= g_lo) return SDRXGPU_OK;
         K12mLaunch M;
         M.L = job->L;
@@ -1985,7 +2087,7 @@ static int launch_k12_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStre
     }
     if (!b->pair) {
         const int gsz = b->W * b->CPW;
-        return launch_k12_range(b, job, st, b->part_ch[p_lo] / gsz, (b->part_ch[p_hi] + gsz - 1) / gsz);
+        return launch_k12_range(b, job, st, b->plan[b->cur_plan].ch[p_lo] / gsz, (b->plan[b->cur_plan].ch[p_hi] + gsz - 1) / gsz);
     }
     ProfScope ps(b, SDRXGPU_K_STAGE12, st);
     const int g_lo = b->part_g[p_lo], g_hi = b->part_g[p_hi];
@@ -2051,8 +2153,8 @@ static int prepare_roll(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, long long n
 static int launch_k123_parts(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, hipStream_t st, int p_lo, int p_hi)
 {
     ProfScope ps(b, SDRXGPU_K_STAGE12, st);
-    const bool whole = p_lo == 0 && p_hi == (int)b->part_ch.size() - 1;
-    const int g_lo = whole ? 0 : b->part_gm[p_lo], g_hi = whole ? b->n_slots_m / (16 * b->mGS) : b->part_gm[p_hi];
+    const bool whole = p_lo == 0 && p_hi == (int)b->plan[b->cur_plan].ch.size() - 1;
+    const int g_lo = whole ? 0 : b->plan[b->cur_plan].gm[p_lo], g_hi = whole ? b->n_slots_m / (16 * b->mGS) : b->plan[b->cur_plan].gm[p_hi];
     if (g_hi <= g_lo) return SDRXGPU_OK;
     K123mLaunch M = job->M3;
     M.args.cg0 = g_lo;
@@ -2116,7 +2218,7 @@ static int launch_stage123(sdrxgpu_bank *b, size_t in_len, hipStream_t st, sdrxg
         const long long q0 = r0 / k->MB;
         job->d0 = (int)(k->MB * q0 + k->MB - 1 - r0);
         if (!defer) {
-            const int rc = launch_k123_parts(b, job, st, 0, (int)b->part_ch.size() - 1);
+            const int rc = launch_k123_parts(b, job, st, 0, (int)b->plan[b->cur_plan].ch.size() - 1);
             if (rc) return rc;
         }
         TailArgs &t = job->t;
@@ -2221,7 +2323,7 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
         }
         job->L = L;
         if (!defer) {
-            const int rc = launch_k12_parts(b, job, st, 0, (int)b->part_ch.size() - 1);
+            const int rc = launch_k12_parts(b, job, st, 0, (int)b->plan[b->cur_plan].ch.size() - 1);
             if (rc) return rc;
         }
 
@@ -2398,7 +2500,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         else
             return fail(SDRXGPU_ERR_HIP, "internal: no k_tail4 for this chain");
         HIPCHK(hipGetLastError());
-    } else if (b->tail_agc && t.n_b > 0 && (b->tail_agc_required || g_banks_on_device[b->device & 63].load() <= 1)) {
+    } else if (b->tail_agc && t.n_b > 0) {
         // tail stages + AGC/demod in one kernel (k_tail_agc): the tile hand-over through LDS replaces the launch boundary
         t.hist_in = b->d_hist[b->hist_cur];
         t.hist_out = b->d_hist[b->hist_cur ^ 1];
@@ -2437,6 +2539,8 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         HIPCHK(hipGetLastError());
         if (last) b->hist_cur ^= 1;
     }
+
+    if (b->mark_after_tail) HIPCHK(hipEventRecord(b->mark_after_tail, b->stream));   // (the decimated IQ rows of [ch_lo, ch_hi) are final)
 
     // ---- AGC -> |.| -> LF AGC ----
     if (t.n_b > 0) {
@@ -2599,6 +2703,7 @@ static int ensure_copy_stream(sdrxgpu_bank *b)
     for (hipEvent_t *e : {&b->ev_h2d, &b->ev_d2h, &b->ev_ring_free[0], &b->ev_ring_free[1]})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t &e : b->ev_part) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t &e : b->ev_iq) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return SDRXGPU_OK;
 }
 
@@ -2614,20 +2719,24 @@ static int run_chunk_host(sdrxgpu_bank *b, size_t in_len, void *iq_out, void *au
     if (rc || !job.valid) return rc;
     const int n_b = job.t.n_b;
     const bool copies = n_b > 0 && (iq_out || audio_out);
-    const int n_all = (int)b->part_ch.size() - 1;
+    b->cur_plan = iq_out ? 0 : 1;                            // which cut of the bank: bank_create's host-parts comment
+    const int n_all = (int)b->plan[b->cur_plan].ch.size() - 1;
     const int n_parts = copies ? n_all : 1;                  // (nothing to copy out: one launch over the whole bank)
     if (n_parts > 1 && (rc = ensure_copy_stream(b))) return rc;
     for (int p = 0; p < n_parts; p++) {
         const int p_lo = copies ? p : 0, p_hi = copies ? p + 1 : n_all;
-        const int ch_lo = b->part_ch[p_lo], ch_hi = b->part_ch[p_hi];
+        const int ch_lo = b->plan[b->cur_plan].ch[p_lo], ch_hi = b->plan[b->cur_plan].ch[p_hi];
         if ((rc = launch_k12_parts(b, &job, b->stream, p_lo, p_hi))) return rc;
         size_t prod = 0;
-        if ((rc = launch_tail(b, &job, nullptr, nullptr, b->keep_stride, 0, &prod, ch_lo, ch_hi, p == n_parts - 1))) return rc;
+        // (the decimated IQ rows are final when the tail kernel is done: their copy need not wait for the AGC recurrence behind it)
+        b->mark_after_tail = (n_parts > 1 && iq_out) ? b->ev_iq[p] : nullptr;
+        rc = launch_tail(b, &job, nullptr, nullptr, b->keep_stride, 0, &prod, ch_lo, ch_hi, p == n_parts - 1);
+        b->mark_after_tail = nullptr;
+        if (rc) return rc;
         if (!copies) continue;
         hipStream_t cs = b->stream;
         if (n_parts > 1) {
             HIPCHK(hipEventRecord(b->ev_part[p], b->stream));
-            HIPCHK(hipStreamWaitEvent(b->copy_stream, b->ev_part[p], 0));
             cs = b->copy_stream;
         }
         const size_t rows = (size_t)(ch_hi - ch_lo);
@@ -2639,9 +2748,16 @@ static int run_chunk_host(sdrxgpu_bank *b, size_t in_len, void *iq_out, void *au
                 return hipMemcpyAsync(d, s_, rows * n_b * elem, hipMemcpyDeviceToHost, cs);
             return hipMemcpy2DAsync(d, out_stride * elem, s_, (size_t)b->keep_stride * elem, (size_t)n_b * elem, rows, hipMemcpyDeviceToHost, cs);
         };
-        if (iq_out) HIPCHK(rows_out(iq_out, b->d_keep, sizeof(float2)));
-        if (audio_out) HIPCHK(rows_out(audio_out, b->d_audio_keep, sizeof(float)));
+        if (iq_out) {
+            if (n_parts > 1) HIPCHK(hipStreamWaitEvent(cs, b->ev_iq[p], 0));
+            HIPCHK(rows_out(iq_out, b->d_keep, sizeof(float2)));
+        }
+        if (audio_out) {
+            if (n_parts > 1) HIPCHK(hipStreamWaitEvent(cs, b->ev_part[p], 0));
+            HIPCHK(rows_out(audio_out, b->d_audio_keep, sizeof(float)));
+        }
     }
+    b->cur_plan = 0;
     if (n_parts > 1) {      // the keep buffers are free again (next chunk, next call) once the copies have read them
         HIPCHK(hipEventRecord(b->ev_d2h, b->copy_stream));
         HIPCHK(hipStreamWaitEvent(b->stream, b->ev_d2h, 0));

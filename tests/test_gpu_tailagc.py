@@ -158,9 +158,67 @@ def test_refusals_and_automatic_choice():
     with pytest.raises(sb.SdrxGpuError) as e:
         sb.ChannelBank(tabs, ch.stage_tuples(), tuning={"tail_agc_cpg": 3})
     assert e.value.code == -1
-    # automatic where it is the faster of the two: mid-size banks
-    # (channels per workgroup: as few as give every CU of the 256 one workgroup at most)
-    for n, want in ((64, 0), (256, 1), (512, 2), (1024, 4), (2048, 0)):
+    # automatic where it is the faster of the two: banks of 1 .. 4 channels per CU of the device that are alone on it when they
+    # are created; channels per workgroup: as few as give every CU one workgroup at most (sdrxgpu.hip, SDRX_TAILAGC_AUTO_*)
+    import torch
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    for n in (n_cu // 4, n_cu, 2 * n_cu, 4 * n_cu, 8 * n_cu):
+        want = 0 if (n < n_cu or n > 4 * n_cu) else 1 if n <= n_cu else 2 if n <= 2 * n_cu else 4
         bk = sb.ChannelBank(sb.translators_for(ch, chains.offsets_cycled(n, ch.N)), ch.stage_tuples())
         assert bk.info().tail_agc == want, (n, bk.info().tail_agc)
         bk.close()
+
+
+def test_the_choice_is_made_at_create_and_kept():
+    """Which of the two (bit-identical) tail sequences a bank runs is decided ONCE, in bank_create, from the banks alive on the device
+    at that moment, and bank_info says which: a second bank that comes and goes between the calls of a stream changes neither the
+    path nor a bit of the first bank's outputs or state; a bank created beside another one keeps the two short kernels."""
+    import torch
+    ch = chains.chain("10")
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    n_ch = 2 * n_cu
+    offs = chains.offsets_cycled(n_ch, ch.N)
+    tabs = sb.translators_for(ch, offs)
+    L, M = ch.block_len, ch.m_total
+    x = _stream(ch, 3, tabs, seed=13, extra=99)
+    lens = [L, 5 * M + 3, L - 5 * M, 17, L - 20]
+    lens.append(len(x) - sum(lens))
+    calls, p = [], 0
+    for n in lens:
+        calls.append(x[p:p + n])
+        p += n
+    level = np.where(np.arange(n_ch) % 4 == 0, 0.0, 6.0).astype(np.float32)
+    mod = [("FM" if c % 3 == 1 else "AM") for c in range(n_ch)]
+    want = _run(tabs, ch, calls, SPLIT, lf_agc=True, modulation=mod)
+    auto = sb.ChannelBank(tabs, ch.stage_tuples(), lf_agc=True, modulation=mod)
+    assert auto.info().tail_agc == 2                    # alone on the device at create: k_tail_agc
+    outs, other = [], None
+    small = sb.translators_for(ch, chains.offsets_cycled(300, ch.N))
+    for k, c in enumerate(calls):
+        if k in (1, 4):                                 # a second bank appears (and works) ...
+            other = sb.ChannelBank(small, ch.stage_tuples())
+            assert other.info().tail_agc == 0           # ... created beside another bank: the two short kernels
+            other.process(x[:L])
+        outs.append(auto.process(c))
+        assert auto.info().tail_agc == 2                # the first bank's path is the one it was created with
+        if k in (2, 4):                                 # ... and goes
+            other.close()
+            other = None
+    got = (np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1), auto.agc_state(), None, auto.info())
+    auto.close()
+    _same(got, want)
+    # whole 512-output chunks with the squelch, the same coming and going
+    kw = dict(squelch=(level,) + tuple(chains.squelch_tables()), modulation=mod)
+    blocks = [x[i * L:(i + 1) * L] for i in range(3)]
+    want = _run(tabs, ch, blocks, SPLIT, **kw)
+    auto = sb.ChannelBank(tabs, ch.stage_tuples(), **kw)
+    assert auto.info().tail_agc == 2
+    outs = []
+    for k, c in enumerate(blocks):
+        other = sb.ChannelBank(small, ch.stage_tuples()) if k == 1 else None
+        outs.append(auto.process(c))
+        if other is not None:
+            other.close()
+    got = (np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1), auto.agc_state(), auto.squelch_state(), auto.info())
+    auto.close()
+    _same(got, want)
