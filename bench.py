@@ -974,10 +974,16 @@ def main():
             if pin:
                 for a_ in (x_host, o_iq, o_au):
                     sb.host_unregister(a_)
+        cuts = {"calls_with_iq": hb.host_parts(False), "audio_only_calls": hb.host_parts(True)}
         hb.close()
+        for label, nbytes in (("pageable", n_ch * 512 * 12), ("page_locked", n_ch * 512 * 12), ("page_locked_audio_only", n_ch * 512 * 4)):
+            # bytes that left the device per second of the WHOLE call (kernels included): the link itself gives 55 - 56 GB/s,
+            # profiles/r06_host_entry_timeline.txt (rocprofv3 --memory-copy-trace of this entry)
+            res[label]["d2h_gbs"] = nbytes / (res[label]["ms_per_block"] * 1e-3) / 1e9
         host_path = {"what": f"sdrxgpu_bank_process: {L * 8 / 1e6:.2f} MB H2D + {n_ch * 512 * 12 / 1e6:.1f} MB D2H per block "
                              f"({n_ch * 512 * 4 / 1e6:.1f} MB audio-only), outputs complete on return; the bank runs in channel "
-                             f"parts (4 at 10 000 channels) so that the D2H of one part overlaps the kernels of the next",
+                             f"parts cut where the rounds of the stage-1/2 kernel end, so that the D2H of one part overlaps the kernels of the next",
+                     "channel_parts": cuts, "d2h_gbs_is": "output bytes / whole call time (the copies alone run at 55 - 56 GB/s: the committed copy trace)",
                      "unit": "Mch-samples/s", **res}
 
     if rank == 0:

@@ -263,7 +263,12 @@ void k_stage12m(const float2 *__restrict__ x_in, const float2 *__restrict__ tabl
                 // __builtin_nontemporal_store in this one).  The s_nop is the compiler's own rule for gfx940 and later, which it cannot
                 // apply to a store it does not see: two wait states between a store of more than 8 bytes and a vector instruction
                 // that overwrites its data registers (without it one set of a 2 304-channel bank came out wrong).
+                // (tools/hazard_lint.py checks the built code for this wait; -DSDRX_LAB_NO_STORE_NOP=1 is the lab build it must fail on)
+#if defined(SDRX_LAB_NO_STORE_NOP) && SDRX_LAB_NO_STORE_NOP
+                asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"((yrow[i] + at) * 8u), "v"(stage[i]), "s"(y2_out) : "memory");
+#else
                 asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"((yrow[i] + at) * 8u), "v"(stage[i]), "s"(y2_out) : "memory");
+#endif
         } else {
 #pragma unroll
             for (int i = i0; i < i1; i++)
