@@ -1049,6 +1049,8 @@ def main():
                 "includes": ("PCIe H2D of every block (host fan-out: the block is in host memory when a step starts)" if use_host else None),
                 "kernel_path": path_main + (f"; {pair_main - 1} conjugate pairs share the mixer" if pair_main else "") +
                                ("; mixer + stage 1 on the f32 matrix pipe" if matrix_main else ""),
+                "kernel_flags": {"fused_tail": bool(fused), "pair_lanes": bool(pair_main), "matrix_pipe": bool(matrix_main), "fused3": matrix_main == 2,
+                                 "tail_agc": int(tailagc_main)},      # (what tools_pmc.sh files a profile under; profile_facts() finds it by these)
                 "realtime_factor": value * 1e6 / (n_ch * world * ch.fs),
                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),   # (set before the HIP runtime started: two banks' streams need queues of their own)
                 "settle_steps": SETTLE_STEPS,    # untimed, before the W warm-up steps (clock settling, see time_bank)

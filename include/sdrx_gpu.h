@@ -22,7 +22,8 @@
  * Threading: a bank is driven by one thread at a time (data_cb is never re-entered,
  * sdrx.cpp:306); different banks may be driven concurrently from different threads, each
  * on its own HIP stream.  There is no global mutable state outside banks but a count of the
- * banks alive per device (it picks between two kernel sequences that give the same bits).
+ * banks alive per device (read once, when a bank is created, to pick between two kernel
+ * sequences that give the same bits).
  *
  * Errors: every function returns 0 on success or a negative SDRXGPU_ERR_* code, in the
  * style of the reference's device layer (src/r820_dev.hpp:61-72).  There is NO CPU fallback:
@@ -59,11 +60,11 @@ extern "C" {
                                             = 32 ms of latency, like one more chunk in sdrx's ring of 8, sdrx.cpp:1742);
                                             sdrxgpu_bank_flush returns the last block.  Same outputs, bit for bit.
                                             The two halves are two chains of work that do not wait for each other inside a
-                                            call, so the INPUT of call k (d_iq_in, or the ingest ring it was written to) is
-                                            read until call k+1 has been enqueued: in the bank's stream order a writer that
-                                            follows call k+1 (or sdrxgpu_bank_flush / _synchronize) is safe, one that follows
-                                            call k only is not -- the rule of sdrxgpu_bank_process_pinned.  Writing block k+1
-                                            into the bank's OTHER ring on the bank's stream right before call k+1 is fine.  */
+                                            call -- except that the bank's stream waits for the copy of d_iq_in into the bank's
+                                            ingest ring: a caller's own input buffer may be rewritten in the bank's stream order
+                                            right after the call, as with the other entries.  A block written straight into the
+                                            ingest ring (sdrxgpu_bank_ingest_buffer: no copy) is read by this call's kernels until
+                                            call k+1 has been enqueued; the bank's OTHER ring is the place for block k+1.       */
 
 #define SDRXGPU_FLAG_FUSED_STAGE3   0x8u  /* large banks of the 10 MS/s chain (where the mixer + stage 1 run on the f32 matrix pipe): run
                                             decimator stages 2 and 3 in that kernel too, as one 119-tap filter, and keep no stage-2
@@ -151,9 +152,12 @@ typedef struct {
     uint32_t m_seg_groups;   /*   pairs x 16 time segments: (2,2), (4,2) or (2,4); 0 = auto                        */
     uint32_t tail_agc;       /* the remaining decimator stage(s) and the AGC / demodulator as ONE kernel (k_tail_agc: tiles of 32
                                 outputs handed from producer waves to the AGC waves through LDS; same bits as k_tail_s + k_agc):
-                                0 = auto (banks of 256 .. 1 024 channels on the separate tail: 3 to 9 % less time per block; below,
-                                the two kernels' own latency chains are shorter than its pipeline's fill, above, its workgroups
-                                no longer fit the chip at once: DESIGN.md 4.10), 1 = never, 2 = require                  */
+                                0 = auto (banks of 1 .. 4 channels per CU -- 256 .. 1 024 on an MI355X -- on the separate tail that are
+                                the only bank on their device WHEN THEY ARE CREATED: 1 to 7 % less time per block, sdrxgpu.hip
+                                SDRX_TAILAGC_AUTO_*; below, the two kernels' own latency chains are shorter than its pipeline's
+                                fill, above, its workgroups no longer fit the chip at once; beside another bank its long-lived
+                                workgroups are in that bank's way: DESIGN.md 4.10), 1 = never, 2 = require.  The choice is made
+                                once, in sdrxgpu_bank_create, and kept: sdrxgpu_bank_info.tail_agc says which sequence runs   */
     uint32_t tail_agc_cpg;   /*   channels per workgroup of that kernel: 1, 2 or 4; 0 = auto                           */
     uint32_t y2_keep_mb;     /* k_stage12m's scratch stores: the sets of a launch written last -- this many MB + 1 of stage-2
                                 outputs -- are ordinary stores (the tail kernel reads them first, out of the Infinity Cache),

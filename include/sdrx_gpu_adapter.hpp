@@ -24,7 +24,7 @@
 //   * a copy of an MSD (Channel assignment, DS's internal copy) is the SAME channel, not a second
 //     delay line;
 //   * use_ftfir (EXPERIMENTAL in the reference, sdrx.cpp:1199) maps to SDRXGPU_FLAG_FTFIR.
-// Optional (one line in main): sdrxgpu::devices() = {0, 1, ..., 7} (or sdrxgpu::use_all_devices()) BEFORE the first block: the
+// Optional (one line in main): sdrxgpu::use_devices(8) (devices() = {0, ..., 7}) or sdrxgpu::use_all_devices() BEFORE the first block: the
 // channel list of every bank is then cut into contiguous ranges over these GPUs (sdrxgpu_multibank_*: per-device state, the block
 // H2D-copied to every device from `in`, every device's rows D2H-copied straight into its slice of the chunk, one worker thread
 // per device as DS has one per channel, ds.hpp:43-77).  Same calls, same bits as on one GPU; no RCCL, no second process.
@@ -35,6 +35,7 @@
 #ifndef SDRX_GPU_ADAPTER_HPP
 #define SDRX_GPU_ADAPTER_HPP
 
+#include <atomic>
 #include <complex>
 #include <cstring>
 #include <iostream>
@@ -50,33 +51,71 @@ namespace sdrxgpu {
 
 using iqsample_t = std::complex<float>;   // reference src/iqsample.hpp:26
 
-inline std::string &last_error()
+namespace detail {
+inline std::mutex &config_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+inline std::string &error_text()
 {
     static std::string e;
     return e;
 }
-
-// 0 (default): every decimate()/addJob() copies its channel's row to `out`.  S > 0: see the header comment.
-inline size_t &chunk_stride()
+inline void set_error(const std::string &what)      // (any thread: a DS worker, the device thread)
 {
-    static size_t v = 0;
+    std::lock_guard<std::mutex> lock(config_mutex());
+    error_text() = what;
+}
+inline bool &all_devices_flag()
+{
+    static bool v = false;
+    return v;
+}
+}   // namespace detail
+
+// The sticky error text (empty: none so far).  A copy, taken under a lock: any thread may ask while another one fails.
+inline std::string last_error()
+{
+    std::lock_guard<std::mutex> lock(detail::config_mutex());
+    return detail::error_text();
+}
+inline void clear_last_error() { detail::set_error(std::string()); }
+
+// 0 (default): every decimate()/addJob() copies its channel's row to `out`.  S > 0: see the header comment.  Set once, before the
+// first block (atomic, so that a late change is at least not a data race: it takes effect with the next block).
+inline std::atomic<size_t> &chunk_stride()
+{
+    static std::atomic<size_t> v{0};
     return v;
 }
 
 // Empty (default): one bank on the current HIP device.  Otherwise the HIP device ordinals the banks created afterwards are cut
-// over, in channel order (sdrxgpu_multibank_create); an ordinal may repeat.
+// over, in channel order (sdrxgpu_multibank_create); an ordinal may repeat.  Read once per bank, at its first block, under the
+// adapter's lock; set it from main before that (use_devices / use_all_devices take the same lock).
 inline std::vector<int32_t> &devices()
 {
     static std::vector<int32_t> v;
     return v;
 }
 
-// every visible GPU (an 8-GPU node: devices() = {0, ..., 7}); for n < 0 nothing changes.  Needs no HIP header here: the count
-// comes from the library's own refusal of the first ordinal that does not exist.
+// devices() = {0, ..., n - 1}; n = 0: back to one bank on the current device; n < 0: nothing changes.  (No HIP header here and no
+// probing: an ordinal that does not exist is refused by sdrxgpu_multibank_create at the first block, SDRXGPU_ERR_NO_DEVICE.)
 inline void use_devices(int n)
 {
+    if (n < 0) return;
+    std::lock_guard<std::mutex> lock(detail::config_mutex());
+    detail::all_devices_flag() = false;
     devices().clear();
     for (int d = 0; d < n; d++) devices().push_back(d);
+}
+
+// every GPU the process can see: the C ABI's n_devices == 0 (sdrxgpu_multibank_create(cfg, NULL, 0, ...)) -- the library counts them.
+inline void use_all_devices()
+{
+    std::lock_guard<std::mutex> lock(detail::config_mutex());
+    detail::all_devices_flag() = true;
+    devices().clear();
 }
 
 namespace detail {
@@ -116,8 +155,9 @@ struct Group {
     void fail(const std::string &what)
     {
         failed = true;
-        last_error() = what + ": " + sdrxgpu_last_error();
-        std::cerr << "Error: sdrxgpu: " << last_error() << std::endl;
+        const std::string text = what + ": " + sdrxgpu_last_error();
+        set_error(text);
+        std::cerr << "Error: sdrxgpu: " << text << std::endl;
     }
 
     void seal()
@@ -145,8 +185,15 @@ struct Group {
         cfg.channels = ch.data();
         sdrxgpu_agc_params_sdrx(&cfg.agc, &cfg.lf_agc);
         cfg.device = -1;
-        if (!devices().empty()) {
-            int rc = sdrxgpu_multibank_create(&cfg, devices().data(), (uint32_t)devices().size(), &multi);
+        std::vector<int32_t> devs;
+        bool all = false;
+        {
+            std::lock_guard<std::mutex> lock(config_mutex());
+            devs = devices();
+            all = all_devices_flag();
+        }
+        if (all || !devs.empty()) {
+            int rc = sdrxgpu_multibank_create(&cfg, all ? nullptr : devs.data(), all ? 0u : (uint32_t)devs.size(), &multi);
             if (rc != SDRXGPU_OK) fail(std::string("sdrxgpu_multibank_create: ") + sdrxgpu_strerror(rc));
             return;
         }
@@ -192,8 +239,8 @@ struct Group {
             produced++;
         } else if (consumed[c] + 1 != produced) {
             failed = true;
-            last_error() = "channels of one bank must be called in lockstep, once per block";
-            std::cerr << "Error: sdrxgpu: " << last_error() << std::endl;
+            set_error("channels of one bank must be called in lockstep, once per block");
+            std::cerr << "Error: sdrxgpu: channels of one bank must be called in lockstep, once per block" << std::endl;
         }
         consumed[c] = produced;
         if (direct_base && out && out != direct_base + c * stride) {
@@ -206,8 +253,8 @@ struct Group {
             direct_base = nullptr;
             chunk_stride() = 0;
             if (last_error().empty()) {
-                last_error() = "chunk_stride(): an output pointer is not base + channel * stride; copying from now on";
-                std::cerr << "Error: sdrxgpu: " << last_error() << std::endl;
+                set_error("chunk_stride(): an output pointer is not base + channel * stride; copying from now on");
+                std::cerr << "Error: sdrxgpu: chunk_stride(): an output pointer is not base + channel * stride; copying from now on" << std::endl;
             }
         }
         if (!direct_base && out) std::memcpy(static_cast<void *>(out), iq.data() + c * stride, out_len * sizeof(iqsample_t));

@@ -42,6 +42,12 @@ struct TailAgcGeom {
     static constexpr int S3N = HAS_A ? ((NR + 1) & ~1) : 0;
     static constexpr int NBUF = HAS_A ? 3 : 4;      // span ring: tiles k (read by the A-wave), k+1, k+2 -- and k-1 where the B-wave reads spans itself
     static constexpr size_t chan_lds = (size_t)(NBUF * S2N + 2 * S3N) * sizeof(float2);     // per channel: span ring + two stage-A buffers
+    // The A-wave computes three neighbouring stage-A outputs per lane from one window of TA + 2 MA entries; for the last lane of a
+    // tile the second and third are past the tile's end (computed, not stored) and their entries can lie up to 2 MA + 3 entries past
+    // the span proper (lead <= 3 + NP) -- for the (5,19,5,45) tail 3 entries past the BUFFER (S2N = 1 024, NP = 1 014).  What they
+    // then read is the head of the same channel's next ring buffer or stage-A buffer: inside the channel's own block, whatever is
+    // there.  A change of RD / NBUF that would let that read leave the block is stopped here.
+    static_assert(!HAS_A || NP + 2 * MA + 3 <= S2N + 2 * S3N, "k_tail_agc: the three-output window's over-read must stay inside the channel's LDS block");
 };
 
 template <bool FM, int NC>
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(tail_agc_waves(NC) * kWave) void k_tail_agc(const T
                             // three NEIGHBOURING outputs per lane: their windows overlap, TA + 2 MA entries are read where three separate
                             // windows take 3 TA (this kernel's waves run out of LDS cycles before anything else: four channels' stage A
                             // and B per CU), and three independent accumulation chains (fma_tap3).  An output past the end works on
-                            // entries inside the buffer and is not stored.
+                            // entries inside the channel's LDS block (TailAgcGeom's static_assert) and is not stored.
                             v2f win[TA + 2 * MA];
                             const v2f *w = s2 + MA * rb;
 #pragma unroll

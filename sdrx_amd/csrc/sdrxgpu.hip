@@ -584,6 +584,7 @@ struct sdrxgpu_bank {
     bool pipelined = false;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_copied = nullptr;          // pipelined mode: the caller's input buffer has been copied into the ingest ring
     struct TailJob {
         bool valid = false;
         TailArgs t;
@@ -727,6 +728,7 @@ static int free_bank(sdrxgpu_bank *b)
         if (e) (void)hipEventDestroy(e);
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+    if (b->ev_copied) (void)hipEventDestroy(b->ev_copied);
     fr(b->d_hist[0]);
     fr(b->d_hist[1]);
     fr(b->d_y3);
@@ -1782,6 +1784,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
         hipError_t e = hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_copied, hipEventDisableTiming);
         if (e != hipSuccess) {
             free_bank(b);
             return fail(SDRXGPU_ERR_HIP, "pipelined-mode stream/event creation failed: %s", hipGetErrorString(e));
@@ -2650,8 +2653,9 @@ static int run_chunk(sdrxgpu_bank *b, size_t in_len, float2 *d_iq_out, float *d_
 //   * round 4 made the bank's stream wait for chain A again at the END of every call (so that "after the call, in stream
 //     order" covered the input): the trace (profiles/r05_trace_pipelined.txt) shows what that cost -- copy -> fork -> stage 1-2
 //     -> join -> next copy became ONE chain through two queues, 10 to 25 us per hand-over, and the mode gained nothing.  Now
-//     the join is taken at the start of the NEXT call, where the tail needs it anyway.  Contract (as for process_pinned): the
-//     input of call k is in use until call k+1 has been enqueued -- or sdrxgpu_bank_flush / _synchronize.
+//     the join is taken at the start of the NEXT call, where the tail needs it anyway.  What the bank's stream does wait for
+//     within the call is the COPY of a caller's own input buffer (round 6): the buffer is the caller's again in
+//     stream order after the call, as with every other entry.
 static int run_chunk_pipelined(sdrxgpu_bank *b, const float2 *src, float2 *d_ingest, size_t in_len, float2 *d_iq_out, float *d_audio_out,
                                size_t out_stride, size_t *produced)
 {
@@ -2662,7 +2666,15 @@ static int run_chunk_pipelined(sdrxgpu_bank *b, const float2 *src, float2 *d_ing
     int rc = launch_tail(b, &b->pending, d_iq_out, d_audio_out, out_stride, 0, produced);
     if (rc) return rc;
     // chain A
-    if (src != d_ingest) HIPCHK(hipMemcpyAsync(d_ingest, src, in_len * sizeof(float2), hipMemcpyDeviceToDevice, b->stream2));
+    if (src != d_ingest) {
+        // a caller's OWN buffer is the caller's again in the bank's stream order once the call has been enqueued (the contract of every
+        // other entry, and of this one before round 5): the bank's stream waits for the copy -- the head of chain A, behind nothing
+        // but ev_fork -- not for the kernels that follow it.  (A block written straight into the ingest ring is read by those kernels:
+        // that ring is free again when the call after next begins, sdrxgpu_bank_ingest_buffer_after.)
+        HIPCHK(hipMemcpyAsync(d_ingest, src, in_len * sizeof(float2), hipMemcpyDeviceToDevice, b->stream2));
+        HIPCHK(hipEventRecord(b->ev_copied, b->stream2));
+        HIPCHK(hipStreamWaitEvent(b->stream, b->ev_copied, 0));
+    }
     sdrxgpu_bank::TailJob job;
     float2 *y2buf = b->y2_cur ? b->d_y2b : b->d_y2;
     rc = launch_stage12(b, in_len, b->stream2, y2buf, &job);

@@ -121,6 +121,8 @@ int main(int argc, char **argv)
     // multi-GPU sdrx adds to main()
     const int n_shards = argc > 5 ? std::atoi(argv[5]) : 0;
     if (n_shards > 0) sdrxgpu::devices() = std::vector<int32_t>((size_t)n_shards, 0);
+    // n_shards < 0: sdrxgpu::use_all_devices() -- every GPU the process sees (the C ABI's n_devices == 0), however many those are
+    if (n_shards < 0) sdrxgpu::use_all_devices();
     const size_t pitch = broken ? CH_IQ_BUF_SIZE + 8 : CH_IQ_BUF_SIZE;
 
     // stage list (what sdrx.cpp:1660-1668 builds for 10 MS/s), read from the file the test wrote
@@ -178,7 +180,7 @@ int main(int argc, char **argv)
     if (use_pool)
         for (auto &ch : channels) ch.msd.decimate(nullptr, 0, nullptr);
     // (... and that second bank on ONE device: pool_equals_serial is then also "cut over devices == not cut", bit for bit)
-    if (use_pool) sdrxgpu::devices().clear();
+    if (use_pool) sdrxgpu::use_devices(0);
     for (int c = 0; c < (int)serial_channels.size(); c++) serial_channels[c].msd = sdrxgpu::MSD(tables[c], stages, false);
     std::vector<iqsample_t> serial_iq((size_t)serial_channels.size() * CH_IQ_BUF_SIZE);
     std::unique_ptr<WorkerPool> pool(use_pool ? new WorkerPool(4) : nullptr);

@@ -48,11 +48,12 @@ def test_data_cb_loop_through_adapter(adapter_bin, mode):
     assert r.stdout.startswith("PASS")
 
 
-@pytest.mark.parametrize("mode,shards", [("serial", 2), ("ds_direct", 2), ("pool", 3), ("pool_direct", 2)])
+@pytest.mark.parametrize("mode,shards", [("serial", 2), ("ds_direct", 2), ("pool", 3), ("pool_direct", 2), ("pool", -1), ("ds", -1)])
 def test_data_cb_loop_through_adapter_cut_over_devices(adapter_bin, mode, shards):
     """The same loop with sdrxgpu::devices() = {0, 0[, 0]}: the bank is a sdrxgpu_multibank (contiguous channel ranges, one
     worker thread and one H2D / D2H per device).  Against the oracle in every mode; the pool modes also compare the cut bank
-    with an uncut one bit for bit."""
+    with an uncut one bit for bit.  shards = -1: sdrxgpu::use_all_devices() -- the C ABI's "every visible device"
+    (n_devices == 0), one shard on this box."""
     exe, taps, _ = adapter_bin
     r = subprocess.run([exe, taps, "33", "3", mode, str(shards)], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)

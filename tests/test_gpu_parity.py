@@ -365,9 +365,9 @@ def test_pipelined_mode_is_bit_identical_one_call_late():
 @pytest.mark.parametrize("n_ch,zero_copy", [(1024, False), (1024, True), (40, True)])
 def test_pipelined_mode_back_to_back_without_waiting(n_ch, zero_copy):
     """The two chains of a pipelined bank run free of each other (round 5): six blocks enqueued back to back, nothing waits
-    until the end.  The contract of the header -- the input of call k is in use until call k+1 has been enqueued -- is what the
-    loop below relies on: distinct input buffers, or (zero_copy) the bank's own two input rings written on the bank's stream
-    right before each call.  Same bits as the serial order."""
+    until the end.  Distinct input buffers, or (zero_copy) the bank's own two input rings written on the bank's stream right before
+    each call -- the ring call k reads is in use until call k+1 has been enqueued, so block k+1 goes into the other one.  Same bits
+    as the serial order."""
     import torch
     ch = chains.chain("10")
     offs = chains.offsets_for_config("c3") if n_ch == 1024 else list(range(-20, 20))
@@ -398,6 +398,43 @@ def test_pipelined_mode_back_to_back_without_waiting(n_ch, zero_copy):
         bank.synchronize()
         torch.cuda.synchronize()
     for k in range(6):
+        got_iq = d_iq[k + 1].cpu().numpy().view(np.complex64)[..., 0]
+        assert np.array_equal(got_iq.view(np.uint32), want[k][0].view(np.uint32)), k
+        assert np.array_equal(d_au[k + 1].cpu().numpy().view(np.uint32), want[k][1].view(np.uint32)), k
+    bank.close()
+
+
+def test_pipelined_mode_one_input_buffer_rewritten_in_stream_order():
+    """A caller's own input buffer is the caller's again in the bank's stream order as soon as the call has been enqueued (ADVICE r5:
+    round 5 had moved the input copy onto the second chain without that guarantee): ONE device buffer, refilled on the bank's
+    stream right after every call -- and scribbled over in between -- gives the serial order's bits."""
+    import torch
+    ch = chains.chain("10")
+    offs = chains.offsets_for_config("c3")
+    tabs = sb.translators_for(ch, offs)
+    L = ch.block_len
+    blocks = [synth.synth_iq(29, b * L, L, 0.25, [tabs[7]], [0.3], ch.N, 10000) for b in range(5)]
+    serial = sb.ChannelBank(tabs, ch.stage_tuples())
+    want = [serial.process(x) for x in blocks]
+    serial.close()
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        bank = sb.ChannelBank(tabs, ch.stage_tuples(), pipelined=True, stream=ts.cuda_stream)
+        staged = [torch.from_numpy(x.view(np.float32).reshape(L, 2).copy()).cuda() for x in blocks]
+        junk = torch.full((L, 2), 1e30, device="cuda")
+        d_x = torch.empty(L, 2, device="cuda")
+        d_iq = [torch.zeros(len(offs), 512, 2, device="cuda") for _ in range(6)]
+        d_au = [torch.zeros(len(offs), 512, device="cuda") for _ in range(6)]
+        torch.cuda.synchronize()
+        for k in range(5):
+            d_x.copy_(staged[k], non_blocking=True)                       # on the bank's stream, behind call k - 1
+            n = bank.process_device(d_x.data_ptr(), L, d_iq[k].data_ptr(), d_au[k].data_ptr(), 512)
+            assert n == (0 if k == 0 else 512)
+            d_x.copy_(junk, non_blocking=True)                            # ... and the buffer is ours again at once
+        assert bank.flush(d_iq[5].data_ptr(), d_au[5].data_ptr(), 512) == 512
+        bank.synchronize()
+        torch.cuda.synchronize()
+    for k in range(5):
         got_iq = d_iq[k + 1].cpu().numpy().view(np.complex64)[..., 0]
         assert np.array_equal(got_iq.view(np.uint32), want[k][0].view(np.uint32)), k
         assert np.array_equal(d_au[k + 1].cpu().numpy().view(np.uint32), want[k][1].view(np.uint32)), k

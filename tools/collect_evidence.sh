@@ -4,6 +4,7 @@
 # ends the script: no further GPU process after it.
 # The microbenchmarks it runs are built beforehand, here (no GPU needed):
 #   for f in valu hbm_read mfma_fir corun; do hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/ubench_$f.bin tools/ubench_$f.hip; done
+#   hipcc -O3 --offload-arch=gfx950 -o tools/lab/pcie_d2h.bin tools/lab/pcie_d2h.hip
 set -u
 cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=8      # (what bench.py sets for itself; under rocprofv3 the runtime starts before the program does)
@@ -43,8 +44,15 @@ prof trace_vector --matrix 1
 ./tools_pmc.sh ev/pmc_matrix > $E/pmc_matrix.log 2>&1 || exit 1
 ./tools_pmc.sh ev/pmc_fused3 --matrix 3 > $E/pmc_fused3.log 2>&1 || exit 1
 ./tools_pmc.sh ev/pmc_vector --matrix 1 > $E/pmc_vector.log 2>&1 || exit 1
+# round 6: counters for BASELINE's own single-GPU configurations (configs[2]'s 1 024 channels = --config c4 at N = 1; 64 channels)
+./tools_pmc.sh ev/pmc_c4 --config c4 > $E/pmc_c4.log 2>&1 || exit 1
+./tools_pmc.sh ev/pmc_64 --channels 64 > $E/pmc_64.log 2>&1 || exit 1
+# round 6: the drop-in entry's copy + kernel trace, the cut sweep behind its automatic choice, the PCIe link by itself
+tools/lab/trace_host_entry.sh ev/host_entry > $E/host_entry.log 2>&1 || exit 1
+step 300 $E/sweep_host_entry.txt python tools/lab/sweep_host_entry.py
+step 120 $E/pcie_d2h.txt tools/lab/pcie_d2h.bin 10
 find $E -name "*kernel_stats.csv" | head
 # keep the merge small: drop the raw traces, keep the stats
 find $E/trace $E/trace_vector $E/trace_fused3 -type f ! -name "*stats*" -delete 2>/dev/null
-find $E -name "*counter_collection.csv" -delete; find $E -name "*agent_info.csv" -delete
+find $E -name "*counter_collection.csv" -delete; find $E -name "*agent_info.csv" -delete; find $E/host_entry -name "*.csv" -delete
 du -sh $E

@@ -28,6 +28,9 @@ cp "$(ls -t $E/trace_vector/runc/*_kernel_stats.csv | head -1)" $P/${T}_kernel_s
 cp $E/pmc_matrix/summary.txt $P/${T}_pmc_summary.txt;                 cp $E/pmc_matrix/traffic.json $P/${T}_traffic.json
 cp $E/pmc_vector/summary.txt $P/${T}_vector_kernels_pmc_summary.txt;  cp $E/pmc_vector/traffic.json $P/${T}_vector_kernels_traffic.json
 cp $E/ubench_valu.txt $P/${T}_ubench_valu.txt; cp $E/ubench_hbm_read.txt $P/${T}_ubench_hbm_read.txt; cp $E/ubench_mfma_fir.txt $P/${T}_ubench_mfma_fir.txt; cp $E/ubench_corun.txt $P/${T}_ubench_corun.txt
+cp $E/pmc_c4/summary.txt $P/${T}_config_c4_pmc_summary.txt;          cp $E/pmc_c4/traffic.json $P/${T}_config_c4_traffic.json
+cp $E/pmc_64/summary.txt $P/${T}_64_channels_pmc_summary.txt;        cp $E/pmc_64/traffic.json $P/${T}_64_channels_traffic.json
+cp $E/host_entry/timeline.txt $P/${T}_host_entry_timeline.txt; cp $E/sweep_host_entry.txt $P/${T}_host_entry_sweep.txt; cp $E/pcie_d2h.txt $P/${T}_pcie_d2h.txt
 tail -3 $E/gpu_tests.log > $P/${T}_gpu_tests_tail.txt
 python3 - "$T" <<'PY'
 import json, sys

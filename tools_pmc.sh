@@ -44,10 +44,10 @@ def bench_line(p):
         if l.startswith('{"metric"'): return json.loads(l)
     return None
 args = " ".join(sys.argv[1:])
-m = re.search(r"--channels (\d+)", args)
-out = {"channels": int(m.group(1)) if m else 10000, "bench_args": args,
-       "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)"}
 b3 = bench_line("$OUT/pass3.log")
+m = re.search(r"--channels (\d+)", args)
+out = {"channels": (b3["config"]["channels_per_gpu"] if b3 else int(m.group(1)) if m else 10000), "bench_args": args,
+       "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)"}
 for k, d in agg.items():
     short = "k_stage12" if "k_stage12" in k else "k_tail" if "k_tail" in k else "k_agc" if "k_agc" in k else None
     if not short or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d: continue
@@ -64,10 +64,8 @@ if "k_stage12" in out:
     out["k_stage12_hbm_bytes_per_launch"] = out["k_stage12"]["hbm_bytes_per_launch"]
     out["sustained_clock_ghz"] = out["k_stage12"].get("clock_ghz")
 if b3:
-    out["fused_tail"] = "fused" in b3["config"]["kernel_path"].split("(")[0]
-    out["pair_lanes"] = "two channels per lane" in b3["config"]["kernel_path"]
-    out["matrix_pipe"] = "matrix pipe" in b3["config"]["kernel_path"]
-    out["fused3"] = "k_stage123m" in b3["config"]["kernel_path"]
+    out.update(b3["config"]["kernel_flags"])         # fused_tail, pair_lanes, matrix_pipe, fused3, tail_agc: what bank_info said
+    out["kernel_path"] = b3["config"]["kernel_path"]
 json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
