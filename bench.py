@@ -873,6 +873,11 @@ def main():
                            "kernel_ms_avg": {n: v[0] for n, v in ke.items()}, "fused_tail": fused_seen[len(o)],
                            "kernel_path": path_of(len(o)),
                            "kernel_ms_note": ("k_tail = k_tail_agc, which contains the AGC recurrence (no k_agc launch)" if tailagc_seen[len(o)] else None)}
+            # HBM bytes per step from the committed rocprofv3 --pmc passes of a bank of this size and kernel path (tools_pmc.sh)
+            pf, pf_src = profile_facts(len(o), fused_seen[len(o)], pair_seen[len(o)], bool(matrix_seen[len(o)]), matrix_seen[len(o)] == 2)
+            if pf:
+                extra[name]["hbm_traffic_step_bytes"] = sum(pf[kk]["hbm_bytes_per_launch"] for kk in ("k_stage12", "k_tail", "k_agc") if kk in pf)
+                extra[name]["traffic_source"] = "committed profile profiles/" + pf_src + " (rocprofv3 --pmc passes of this build, not this run)"
 
     if world == 1 and not args.no_extra_configs and plan.name == "headline" and tuning is None and matrix_main == 1:
         # the same workload with SDRXGPU_FLAG_FUSED_STAGE3 (k_stage123m + k_tail_c: no stage-2 scratch; opt-in because of its rounding,

@@ -98,5 +98,6 @@ def test_200_blocks_with_active_lf_agc_block_by_block(oracle):
     margin("long_stream_200_blocks_lf_agc_block_by_block", iq=worst_iq, audio_per_block=worst_au)
     # One block (512 steps) of this loop from IDENTICAL state already separates two builds of one code base by up to
     # 9.1e-6 (the oracle's -O2 and -O3 -march builds, 60 blocks of this stream); the GPU (FMA contraction like the
-    # reference's -march=native build, 1-ulp v_sqrt_f32) stays within 1.4e-5 of the plain build over these 200 blocks
-    assert worst_iq <= RTOL and worst_au <= 3 * RTOL
+    # reference's -march=native build, 1-ulp v_sqrt_f32) stays within 1.3833e-5 of the plain build over these 200 blocks (the same
+    # figure in every round since round 2): that + 20 %, 1.66e-5
+    assert worst_iq <= RTOL and worst_au <= 1.66e-5

@@ -55,5 +55,6 @@ def test_random_configuration_vs_oracle(oracle, seed):
     margin(f"random[{seed}] rate={ch.rate} lf={int(lf)} ftfir={int(ftfir)} fir={int(fir is not None)}", iq=w_iq, audio=w_au)
     # An ACTIVE LF AGC amplifies rounding (two builds of the reference itself drift apart by 1.7e-5 within 5 blocks and 4e-3
     # within 16, tests/test_oracle.py::test_active_lf_agc_is_ill_conditioned_in_the_reference_itself; worst seen here over
-    # these 1.2 - 2.6 blocks: 1.06e-5): twice the tolerance for those cases only
-    assert w_iq <= RTOL and w_au <= (2 * RTOL if lf else RTOL), (seed, w_iq, w_au)
+    # these 1.2 - 2.6 blocks: 1.0624e-5, seed 11, the same on every box and in every round since round 2): that measured worst
+    # + 20 % for those cases only -- 1.28e-5, not a round 2e-5
+    assert w_iq <= RTOL and w_au <= (1.28e-5 if lf else RTOL), (seed, w_iq, w_au)
