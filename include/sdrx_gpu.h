@@ -25,6 +25,30 @@
  * banks alive per device (read once, when a bank is created, to pick between two kernel
  * sequences that give the same bits).
  *
+ * NUMERICAL CONTRACT (one table; INTEGRATION.md 6 has the measurements, tests/test_gpu_pairs_stress.py enforces it on fixtures
+ * from the compiled reference).  All paths compute the reference's chain in exact fp32 operations; they differ in the ORDER of
+ * summation, as the reference's own two builds do (Release: AVX2 + FMA; portable: source order).  "spread" = the distance
+ * between those two builds on the case at hand; comparator |got - ref| / max(|ref|, rms of the channel), ref = portable build.
+ *
+ *   path                     runs when                                   <= 1e-5 where        never beyond    cut-       layout-
+ *                                                                        spread <=            k x spread      invariant  invariant
+ *   vector kernels           < 1 024 channels, few +k/-k pairs, every    0.5e-5               1.7 (<= 1.41)   yes        yes
+ *    (reference's order)     chain but 10 MS/s, or
+ *                            SDRXGPU_FLAG_REFERENCE_ORDER
+ *   k_stage12m               10 MS/s, >= 1 024 channels mostly in        0.5e-5 (worst case   2.1 (<= 1.75)   yes        within the
+ *    (f32 matrix pipe)       +k/-k pairs: automatic                      1.06e-5 / 1.27e-5)                              family (*)
+ *   k_stage123m              only SDRXGPU_FLAG_FUSED_STAGE3              0.3e-5               3.5 (<= 3.15)   no (to     within the
+ *    (+ stages 2-3 fused)                                                                                     tolerance) family
+ *   k_stage12m6              only tuning.matrix_pipe = 2 on a 6 MS/s     -- (1.38e-5 /        4 (<= 3.43)     yes        within the
+ *    (6 MS/s, matrix pipe)   bank                                        1.78e-5 worst)                                  family
+ *
+ *   cut-invariant: the same bits however the stream is cut into calls.  layout-invariant: a channel's bits do not depend on who
+ *   else is in the bank, on the bank's size or on how a channel list is sharded over GPUs.  (*) which family a bank takes depends
+ *   on its channel list; pin tuning.matrix_pipe where bits must agree across layouts (a sdrxgpu_multibank pins it by itself).
+ *   SDRXGPU_FLAG_REFERENCE_ORDER is THE way to hold 1e-5 wherever the reference's own builds allow it, on every channel, for 15 %
+ *   of a 10 000-channel block.  On BASELINE's synthetic inputs every path is <= 4.7e-6.  Audio with SDRXGPU_FLAG_LF_AGC_ACTIVE is
+ *   ill-conditioned in the reference itself (its two builds are 1.7e-5 apart after 5 blocks): measured <= 1.4e-5 block by block.
+ *
  * Errors: every function returns 0 on success or a negative SDRXGPU_ERR_* code, in the
  * style of the reference's device layer (src/r820_dev.hpp:61-72).  There is NO CPU fallback:
  * without a usable gfx950 device sdrxgpu_bank_create fails with SDRXGPU_ERR_NO_DEVICE.
