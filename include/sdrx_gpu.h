@@ -19,6 +19,9 @@
  * Plain C: no C++ or torch types cross this boundary.  IQ samples are interleaved
  * {re, im} float32 = std::complex<float> = reference iqsample_t (src/iqsample.hpp:26).
  *
+ * Devices: every entry makes the bank's device current for its own duration and restores the caller's current HIP device on
+ * return.
+ *
  * Threading: a bank is driven by one thread at a time (data_cb is never re-entered,
  * sdrx.cpp:306); different banks may be driven concurrently from different threads, each
  * on its own HIP stream.  There is no global mutable state outside banks but a count of the

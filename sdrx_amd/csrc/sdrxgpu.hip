@@ -501,6 +501,24 @@ static std::atomic<int> g_banks_on_device[64];
 // ------------------------------------------------------------------------------------------
 // the bank
 // ------------------------------------------------------------------------------------------
+// Every entry that touches a bank makes the bank's device current for its own duration and puts the caller's back on return: a
+// thread that drives banks on several devices, or does HIP work of its own, keeps the current device it chose.
+struct DeviceGuard {
+    int prev = -1, dev;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int d) : dev(d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 struct ProfSpan {
     hipEvent_t a, b;
     int kernel;
@@ -863,7 +881,8 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
     int dev = cfg->device;
     if (dev < 0) HIPCHK(hipGetDevice(&dev));
     if (dev >= ndev) return fail(SDRXGPU_ERR_NO_DEVICE, "bank_create: device %d of %d", dev, ndev);
-    HIPCHK(hipSetDevice(dev));
+    DeviceGuard on_device(dev);             // (the caller's current device is restored on return)
+    HIPCHK(on_device.err);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, dev));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -1835,7 +1854,7 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
 extern "C" int sdrxgpu_bank_destroy(sdrxgpu_bank *b)
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_destroy: null bank");
-    (void)hipSetDevice(b->device);
+    DeviceGuard on_device(b->device);
     const int n_bad = free_bank(b);
     if (n_bad) return fail(SDRXGPU_ERR_HIP, "bank_destroy: %d hipFree call(s) failed", n_bad);
     return SDRXGPU_OK;
@@ -1844,7 +1863,8 @@ extern "C" int sdrxgpu_bank_destroy(sdrxgpu_bank *b)
 extern "C" int sdrxgpu_bank_reset(sdrxgpu_bank *b)
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_reset: null bank");
-    HIPCHK(hipSetDevice(b->device));
+    DeviceGuard on_device(b->device);       // (the caller's current device is the caller's: restored on return)
+    HIPCHK(on_device.err);
     return init_state(b);
 }
 
@@ -1924,7 +1944,8 @@ extern "C" int sdrxgpu_bank_get_host_parts(sdrxgpu_bank *b, int audio_only, uint
 extern "C" int sdrxgpu_bank_get_gains(sdrxgpu_bank *b, float *agc_gain, float *lf_gain)
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_gains: null bank");
-    HIPCHK(hipSetDevice(b->device));
+    DeviceGuard on_device(b->device);       // (the caller's current device is the caller's: restored on return)
+    HIPCHK(on_device.err);
     std::vector<float4> st(b->n_ch);
     HIPCHK(hipMemcpyAsync(st.data(), b->d_state, st.size() * sizeof(float4), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1938,7 +1959,8 @@ extern "C" int sdrxgpu_bank_get_gains(sdrxgpu_bank *b, float *agc_gain, float *l
 extern "C" int sdrxgpu_bank_get_agc_state(sdrxgpu_bank *b, float *agc_gain, float *agc_power, float *lf_gain, float *lf_power)
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_agc_state: null bank");
-    HIPCHK(hipSetDevice(b->device));
+    DeviceGuard on_device(b->device);       // (the caller's current device is the caller's: restored on return)
+    HIPCHK(on_device.err);
     std::vector<float4> st(b->n_ch);
     HIPCHK(hipMemcpyAsync(st.data(), b->d_state, st.size() * sizeof(float4), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -2792,7 +2814,8 @@ static int process_impl(sdrxgpu_bank *b, const void *in, bool in_is_host, size_t
         const int rc = validate_call(b, in_len, iq_out || audio_out, out_stride);
         if (rc) return rc;
     }
-    HIPCHK(hipSetDevice(b->device));
+    DeviceGuard on_device(b->device);       // (the caller's current device is the caller's: restored on return)
+    HIPCHK(on_device.err);
     if (b->mix && !b->pipelined) b->mix_frames = 0;
     b->ring_busy[0] = b->ring_busy[1] = false;      // (sdrxgpu_bank_process_pinned's bookkeeping does not cover these calls)
     ProfScope total(b, SDRXGPU_K_TOTAL);
@@ -2842,7 +2865,8 @@ extern "C" int sdrxgpu_bank_process_pinned(sdrxgpu_bank *b, const sdrxgpu_iq *iq
         return fail(SDRXGPU_ERR_UNSUPPORTED, "process_pinned: a bank with mix-down takes at most max_in_len = %u samples per call", b->max_chunk);
     int rc = validate_call(b, in_len, d_iq_out || d_audio_out, out_stride);
     if (rc) return rc;
-    HIPCHK(hipSetDevice(b->device));
+    DeviceGuard on_device(b->device);       // (the caller's current device is the caller's: restored on return)
+    HIPCHK(on_device.err);
     if ((rc = ensure_copy_stream(b))) return rc;
     if (b->h2d_pending) {       // the previous call's host buffer is the caller's again once this call has begun
         HIPCHK(hipEventSynchronize(b->ev_h2d));
@@ -2893,7 +2917,8 @@ extern "C" int sdrxgpu_bank_flush(sdrxgpu_bank *b, void *d_iq_out, void *d_audio
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "flush: null bank");
     if (b->pending.valid && (d_iq_out || d_audio_out) && (size_t)b->pending.t.n_b > out_stride)
         return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "flush: %d outputs per channel but out_stride is %zu", b->pending.t.n_b, out_stride);
-    HIPCHK(hipSetDevice(b->device));
+    DeviceGuard on_device(b->device);       // (the caller's current device is the caller's: restored on return)
+    HIPCHK(on_device.err);
     size_t produced = 0;
     if (b->pipelined && b->pending.valid) HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join, 0));   // the pending block's chain A
     int rc = launch_tail(b, &b->pending, (float2 *)d_iq_out, (float *)d_audio_out, out_stride, 0, &produced);
@@ -2943,7 +2968,8 @@ extern "C" int sdrxgpu_bank_get_mix(sdrxgpu_bank *b, float *mix_f32, int16_t *mi
     if (n_frames) *n_frames = n;
     if ((mix_f32 || mix_s16) && cap_frames < n)
         return fail(SDRXGPU_ERR_OUT_TOO_SMALL, "bank_get_mix: %zu frames but room for %zu", n, cap_frames);
-    HIPCHK(hipSetDevice(b->device));
+    DeviceGuard on_device(b->device);       // (the caller's current device is the caller's: restored on return)
+    HIPCHK(on_device.err);
     if (mix_f32 && n) HIPCHK(hipMemcpyAsync(mix_f32, b->d_mix_f32, n * 2 * sizeof(float), hipMemcpyDeviceToHost, b->stream));
     if (mix_s16 && n) HIPCHK(hipMemcpyAsync(mix_s16, b->d_mix_s16, n * 2 * sizeof(short), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -2954,7 +2980,8 @@ extern "C" int sdrxgpu_bank_get_squelch(sdrxgpu_bank *b, float *snr_db, unsigned
 {
     if (!b) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_squelch: null bank");
     if (!b->squelch) return fail(SDRXGPU_ERR_INVALID_ARG, "bank_get_squelch: the bank was created without squelch");
-    HIPCHK(hipSetDevice(b->device));
+    DeviceGuard on_device(b->device);       // (the caller's current device is the caller's: restored on return)
+    HIPCHK(on_device.err);
     std::vector<uchar2> st(b->n_ch);
     if (snr_db) HIPCHK(hipMemcpyAsync(snr_db, b->d_snr, (size_t)b->n_ch * sizeof(float), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipMemcpyAsync(st.data(), b->d_sql, st.size() * sizeof(uchar2), hipMemcpyDeviceToHost, b->stream));
