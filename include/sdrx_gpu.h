@@ -25,8 +25,8 @@
  * Threading: a bank is driven by one thread at a time (data_cb is never re-entered,
  * sdrx.cpp:306); different banks may be driven concurrently from different threads, each
  * on its own HIP stream.  There is no global mutable state outside banks but a count of the
- * banks alive per device (read once, when a bank is created, to pick between two kernel
- * sequences that give the same bits).
+ * banks alive per device (read when a bank is created and once more when its first block
+ * is processed, to pick between two kernel sequences that give the same bits).
  *
  * NUMERICAL CONTRACT (one table; INTEGRATION.md 6 has the measurements, tests/test_gpu_pairs_stress.py enforces it on fixtures
  * from the compiled reference).  All paths compute the reference's chain in exact fp32 operations; they differ in the ORDER of
@@ -180,11 +180,12 @@ typedef struct {
     uint32_t tail_agc;       /* the remaining decimator stage(s) and the AGC / demodulator as ONE kernel (k_tail_agc: tiles of 32
                                 outputs handed from producer waves to the AGC waves through LDS; same bits as k_tail_s + k_agc):
                                 0 = auto (banks of 1 .. 4 channels per CU -- 256 .. 1 024 on an MI355X -- on the separate tail that are
-                                the only bank on their device WHEN THEY ARE CREATED: 1 to 7 % less time per block, sdrxgpu.hip
+                                the only bank on their device when their FIRST BLOCK is processed: 1 to 7 % less time per block, sdrxgpu.hip
                                 SDRX_TAILAGC_AUTO_*; below, the two kernels' own latency chains are shorter than its pipeline's
                                 fill, above, its workgroups no longer fit the chip at once; beside another bank its long-lived
                                 workgroups are in that bank's way: DESIGN.md 4.10), 1 = never, 2 = require.  The choice is made
-                                once, in sdrxgpu_bank_create, and kept: sdrxgpu_bank_info.tail_agc says which sequence runs   */
+                                once -- provisionally at create, finally with the bank's first block, when an application has
+                                created all its banks -- and kept: sdrxgpu_bank_info.tail_agc says which sequence runs        */
     uint32_t tail_agc_cpg;   /*   channels per workgroup of that kernel: 1, 2 or 4; 0 = auto                           */
     uint32_t y2_keep_mb;     /* k_stage12m's scratch stores: the sets of a launch written last -- this many MB + 1 of stage-2
                                 outputs -- are ordinary stores (the tail kernel reads them first, out of the Infinity Cache),

@@ -465,10 +465,12 @@ static long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) 
 // Banks alive per device.  The one thing it decides is a choice between two bit-identical kernel sequences (k_tail_agc or
 // k_tail_s + k_agc, launch_tail): a bank ALONE on its GPU is 4 % faster per block with the fused kernel, two banks sharing a GPU
 // (BASELINE configs[4]) are 12 % slower with it -- its long-lived workgroups get in the way of the other bank's stage-1/2 launch,
-// under which the two short kernels hide anyway (0.219 against 0.194 ms per step of both banks).  The choice is made ONCE, in
-// bank_create, from the banks alive on the device at that moment (round 5 looked at the counter at every launch: the path could
-// then change between two calls of one stream, an idle spare bank switched the kernel off, and bank_info said nothing of it):
-// a bank keeps the sequence it was created with, and sdrxgpu_bank_info.tail_agc says which.
+// under which the two short kernels hide anyway (0.219 against 0.194 ms per step of both banks).  The choice is made ONCE per bank
+// (round 5 looked at the counter at every launch: the path could then change between two calls of one stream, and bank_info said
+// nothing of it): provisionally in bank_create, finally when the bank's FIRST block is processed -- an application creates its
+// banks, then streams (sdrx.cpp:1680-1714, then data_cb), so that is the moment all of a device's banks exist: BASELINE
+// configs[4]'s two banks per GPU both keep the two kernels, whichever was created first.  From then on the bank keeps its
+// sequence whatever is created or destroyed beside it, and sdrxgpu_bank_info.tail_agc says which.
 #include <atomic>
 static std::atomic<int> g_banks_on_device[64];
 
@@ -566,6 +568,8 @@ struct sdrxgpu_bank {
     int hist_cur = 0;
     // tail stages + AGC/demod as ONE kernel (k_tail_agc, kernels_tailagc.hpp): banks on the separate tail whose tail is a latency chain
     bool tail_agc = false;
+    bool tail_agc_required = false;           //   tuning.tail_agc = 2: whoever else is on the device
+    bool tail_agc_final = false;              //   the first block has been processed: the choice stands
     bool counted = false;                     // this bank is in g_banks_on_device
     int ta_cpg = 4;                           //   channels per workgroup of that kernel
     int ta_nt = 2;                            //   its producer waves per workgroup
@@ -1357,7 +1361,8 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
             return fail(SDRXGPU_ERR_UNSUPPORTED, "bank_create: tuning.tail_agc = 2, but k_tail_agc is built for the separate tail of the reference's "
                         "chains (not with stage 3 fused into the stage-1/2 kernel, not with tail_generic; %zu B of LDS)", lds_max);
         }
-        // automatic: mid-size banks that are the only bank on their device when they are created (the counter above)
+        // automatic: mid-size banks that are the only bank on their device -- now, and still when their first block comes (launch_tail)
+        b->tail_agc_required = tune.tail_agc == 2;
         const bool alone = !(b->device >= 0 && b->device < 64) || g_banks_on_device[b->device].load() == 0;
         b->tail_agc = can && (tune.tail_agc == 2 || (tune.tail_agc == 0 && alone && (int)b->n_ch >= SDRX_TAILAGC_AUTO_MIN_CU * n_cu &&
                                                      (int)b->n_ch <= SDRX_TAILAGC_AUTO_MAX_CU * n_cu));
@@ -2412,6 +2417,16 @@ static int launch_stage12(sdrxgpu_bank *b, size_t in_len, hipStream_t st, float2
     return SDRXGPU_OK;
 }
 
+// k_tail_agc or k_tail_s + k_agc: settled when the bank's first block is processed (the comment at g_banks_on_device)
+static bool tail_agc_now(sdrxgpu_bank *b)
+{
+    if (!b->tail_agc_final) {
+        if (b->tail_agc && !b->tail_agc_required && b->device >= 0 && b->device < 64 && g_banks_on_device[b->device].load() > 1) b->tail_agc = false;
+        b->tail_agc_final = true;
+    }
+    return b->tail_agc;
+}
+
 // Tail stage(s) + AGC/demod of a prepared job on the bank's stream, outputs to the given device pointers.
 // [ch_lo, ch_hi): the channels of this launch (ch_hi < 0: the whole bank); `last`: the last (or only) part of the chunk --
 // what concerns the whole bank (history copy, squelch / audio FIR / mix-down, the output count) happens with it.
@@ -2525,7 +2540,7 @@ static int launch_tail(sdrxgpu_bank *b, sdrxgpu_bank::TailJob *job, float2 *d_iq
         else
             return fail(SDRXGPU_ERR_HIP, "internal: no k_tail4 for this chain");
         HIPCHK(hipGetLastError());
-    } else if (b->tail_agc && t.n_b > 0) {
+    } else if (tail_agc_now(b) && t.n_b > 0) {
         // tail stages + AGC/demod in one kernel (k_tail_agc): the tile hand-over through LDS replaces the launch boundary
         t.hist_in = b->d_hist[b->hist_cur];
         t.hist_out = b->d_hist[b->hist_cur ^ 1];

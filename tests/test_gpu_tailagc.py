@@ -169,10 +169,12 @@ def test_refusals_and_automatic_choice():
         bk.close()
 
 
-def test_the_choice_is_made_at_create_and_kept():
-    """Which of the two (bit-identical) tail sequences a bank runs is decided ONCE, in bank_create, from the banks alive on the device
-    at that moment, and bank_info says which: a second bank that comes and goes between the calls of a stream changes neither the
-    path nor a bit of the first bank's outputs or state; a bank created beside another one keeps the two short kernels."""
+def test_the_choice_is_made_once_and_kept():
+    """Which of the two (bit-identical) tail sequences a bank runs is decided ONCE -- provisionally in bank_create, finally when its
+    first block is processed, from the banks alive on the device at that moment -- and bank_info says which: a second bank that comes
+    and goes between the calls of a stream changes neither the path nor a bit of the first bank's outputs or state; a bank created
+    beside another one keeps the two short kernels; and two banks created before either has seen a block (BASELINE configs[4]'s two
+    streams per GPU) both keep them, whichever was created first."""
     import torch
     ch = chains.chain("10")
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
@@ -207,6 +209,21 @@ def test_the_choice_is_made_at_create_and_kept():
     got = (np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1), auto.agc_state(), None, auto.info())
     auto.close()
     _same(got, want)
+    # two banks, then their first blocks: neither takes the fused kernel, and the one created first says so once it has run
+    first = sb.ChannelBank(tabs, ch.stage_tuples())
+    assert first.info().tail_agc == 2                   # (provisional: alone when it was created)
+    second = sb.ChannelBank(tabs, ch.stage_tuples())
+    assert second.info().tail_agc == 0
+    a1, a2 = first.process(x[:L]), second.process(x[:L])
+    assert first.info().tail_agc == 0 and second.info().tail_agc == 0
+    second.close()
+    b1 = first.process(x[L:2 * L])
+    assert first.info().tail_agc == 0                   # ... and alone again it stays with what it ran
+    first.close()
+    assert np.array_equal(_bits(a1[0]), _bits(a2[0])) and np.array_equal(_bits(a1[1]), _bits(a2[1]))
+    plain = _run(tabs, ch, [x[:L], x[L:2 * L]], SPLIT)
+    assert np.array_equal(_bits(np.concatenate([a1[0], b1[0]], axis=1)), _bits(plain[0]))
+    assert np.array_equal(_bits(np.concatenate([a1[1], b1[1]], axis=1)), _bits(plain[1]))
     # whole 512-output chunks with the squelch, the same coming and going
     kw = dict(squelch=(level,) + tuple(chains.squelch_tables()), modulation=mod)
     blocks = [x[i * L:(i + 1) * L] for i in range(3)]
