@@ -7,7 +7,8 @@ two summation orders of the same arithmetic, each within its own error of the ex
 cases in 420 s on one MI355X (seed 11; 8 063 more with seed 7), worst 4.5e-6 against the oracle, 5.9e-6 against the vector
 kernels, every split and every workgroup shape bit-identical.  Round 5: the scratch stores' streaming cut drawn at random (7 648
 cases, seed 77); a third argument "6" runs the 6 MS/s chain through k_stage12m6 instead: 8 003 cases in 300 s (seed 66), every
-split and lane length bit-identical, worst 4.5e-6 against the oracle, 5.7e-6 against the vector kernels (profiles/r05_m6.txt)."""
+split and lane length bit-identical, worst 4.5e-6 against the oracle, 5.7e-6 against the vector kernels (profiles/r05_m6.txt).
+Round 6: the host entry's channel parts drawn at random (automatic / equal / explicit cuts; banks up to 7 000 channels)."""
 import os
 import random
 import sys
@@ -27,7 +28,7 @@ ch = chains.chain(RATE)
 L = ch.block_len
 while time.time() < t_end:
     ftfir = RATE == "10" and rng.random() < 0.15
-    n_ch = rng.choice([1, 2, 3, 17, 31, 32, 33, 64, 65, 100, 257, 1023, 1024, 1025, 1500, 2049, 3000])
+    n_ch = rng.choice([1, 2, 3, 17, 31, 32, 33, 64, 65, 100, 257, 1023, 1024, 1025, 1500, 2049, 3000, 2049, 3000, 4500, 7000])
     kind = rng.choice(["cycled", "random", "mirror", "same"])
     if kind == "cycled":
         offs = chains.offsets_cycled(n_ch, ch.N)
@@ -58,8 +59,18 @@ while time.time() < t_end:
         outs = [b.process(x) for x in blocks]
         b.close()
         return np.concatenate([o[0] for o in outs], 1), np.concatenate([o[1] for o in outs], 1), info
-    ref = run({"matrix_pipe": 2, "y2_keep_mb": 0xFFFFFFFF}, 0, whole)
-    got = run({"matrix_pipe": 2, "m_slot_groups": gs, "m_seg_groups": gt, "y2_keep_mb": keep}, hint, cuts)
+    # round 6: the host entry's channel parts drawn at random too (banks of 2 048 channels and more run in parts: automatic cuts
+    # by rounds, equal parts, or explicit boundaries anywhere; a pair belongs to the part of its first channel)
+    parts = {}
+    if n_ch >= 2048:
+        how = rng.choice(["auto", "equal", "explicit", "explicit"])
+        if how == "equal":
+            parts = {"host_parts": rng.randrange(1, 6)}
+        elif how == "explicit":
+            b_ = sorted(set(rng.randrange(64, n_ch - 64) // 64 * 64 for _ in range(rng.randrange(1, 6))))
+            parts = {"host_parts": len(b_) + 1, "host_part_ch": tuple(b_)}
+    ref = run({"matrix_pipe": 2, "y2_keep_mb": 0xFFFFFFFF, "host_parts": 1}, 0, whole)
+    got = run({"matrix_pipe": 2, "m_slot_groups": gs, "m_seg_groups": gt, "y2_keep_mb": keep, **parts}, hint, cuts)
     vec = run({"matrix_pipe": 1}, 0, whole)
     assert ref[2].matrix_pipe == 1 and got[2].matrix_pipe == 1 and vec[2].matrix_pipe == 0
     ok = np.array_equal(ref[0].view(np.uint32), got[0].view(np.uint32)) and np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32))
@@ -74,7 +85,7 @@ while time.time() < t_end:
     n_cases += 1
     good = ok and max(errs) < 1e-5 and e_vec < 1e-5
     print(("OK  " if good else "FAIL"), "ftfir" if ftfir else "     ", "n_ch", n_ch, kind, "hint", hint, "shape", (gs, gt), "keep", keep, "lf", lf, "calls", len(cuts),
-          "slots", got[2].m_slots, "oracle %.2e" % max(errs), "vector kernels %.2e" % e_vec, flush=True)
+          "slots", got[2].m_slots, "parts", parts.get("host_part_ch", parts.get("host_parts", "auto")), "oracle %.2e" % max(errs), "vector kernels %.2e" % e_vec, flush=True)
     if not good:
         sys.exit(1)
 print("cases", n_cases)

@@ -53,6 +53,15 @@ def test_strerror_and_version(lib):
     assert b"gfx950" in lib.sdrxgpu_version()
 
 
+def test_null_handles_are_refused_not_dereferenced(lib):
+    import ctypes as C
+    n = C.c_size_t(7)
+    assert lib.sdrxgpu_bank_get_host_parts(None, 0, None, 0, C.byref(n)) == -1
+    assert lib.sdrxgpu_bank_synchronize(None) == -1 and lib.sdrxgpu_bank_destroy(None) == -1
+    assert lib.sdrxgpu_multibank_synchronize(None) == -1 and lib.sdrxgpu_multibank_destroy(None) == -1
+    assert b"null" in lib.sdrxgpu_last_error()
+
+
 def test_make_translator_matches_oracle(lib, oracle):
     """Host-side table builder == the oracle's restatement of sdrx.cpp:1686-1689 (same libm)."""
     for rate, off in (("10", 1), ("10", -415), ("10", 480), ("2.4", 37), ("1.44", -11), ("0.96", 200)):
