@@ -652,8 +652,6 @@ struct sdrxgpu_bank {
     int cur_plan = 0;
     std::vector<int> part_g;                          // slot-group boundaries of the parts (two channels per lane: plan[0] only)
     hipStream_t copy_stream = nullptr;
-    hipStream_t copy_stream2 = nullptr;               // host entry: the audio rows' copies (the next copy is set up while one runs)
-    hipEvent_t ev_d2h2 = nullptr;
     int host_parts = 0;                               // tuning.host_parts (0 = auto)
     size_t y2_keep = 0;                               // bytes of a k_stage12m launch's scratch (the sets written last) stored without the streaming hint
     hipEvent_t ev_part[8] = {};                       // kernels of a channel part are done
@@ -725,7 +723,6 @@ static int free_bank(sdrxgpu_bank *b)
     // every stream of the bank first (a pipelined bank's second chain is not ordered behind the bank's stream any more)
     if (b->stream2) (void)hipStreamSynchronize(b->stream2);
     if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
-    if (b->copy_stream2) (void)hipStreamSynchronize(b->copy_stream2);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (ProfSpan &s : b->prof_pending) {
         (void)hipEventDestroy(s.a);
@@ -745,11 +742,6 @@ static int free_bank(sdrxgpu_bank *b)
         (void)hipStreamSynchronize(b->copy_stream);
         (void)hipStreamDestroy(b->copy_stream);
     }
-    if (b->copy_stream2) {
-        (void)hipStreamSynchronize(b->copy_stream2);
-        (void)hipStreamDestroy(b->copy_stream2);
-    }
-    if (b->ev_d2h2) (void)hipEventDestroy(b->ev_d2h2);
     for (hipEvent_t e : {b->ev_h2d, b->ev_d2h, b->ev_ring_free[0], b->ev_ring_free[1]})
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->ev_part)
@@ -801,7 +793,6 @@ static int init_state(sdrxgpu_bank *b)
 {
     if (b->stream2) HIPCHK(hipStreamSynchronize(b->stream2));
     if (b->copy_stream) HIPCHK(hipStreamSynchronize(b->copy_stream));
-    if (b->copy_stream2) HIPCHK(hipStreamSynchronize(b->copy_stream2));
     b->ring_busy[0] = b->ring_busy[1] = false;
     b->h2d_pending = false;
     b->pending.valid = false;
@@ -1888,7 +1879,6 @@ extern "C" int sdrxgpu_bank_synchronize(sdrxgpu_bank *b)
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->stream2) HIPCHK(hipStreamSynchronize(b->stream2));
     if (b->copy_stream) HIPCHK(hipStreamSynchronize(b->copy_stream));
-    if (b->copy_stream2) HIPCHK(hipStreamSynchronize(b->copy_stream2));
     b->h2d_pending = false;
     return SDRXGPU_OK;
 }
@@ -2755,15 +2745,10 @@ static int validate_call(const sdrxgpu_bank *b, size_t in_len, bool has_outs, si
     return SDRXGPU_OK;
 }
 
-#ifndef SDRX_LAB_TWO_COPY_STREAMS
-#define SDRX_LAB_TWO_COPY_STREAMS 1
-#endif
 static int ensure_copy_stream(sdrxgpu_bank *b)
 {
     if (b->copy_stream) return SDRXGPU_OK;
     HIPCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&b->copy_stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&b->ev_d2h2, hipEventDisableTiming));
     for (hipEvent_t *e : {&b->ev_h2d, &b->ev_d2h, &b->ev_ring_free[0], &b->ev_ring_free[1]})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t &e : b->ev_part) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2817,9 +2802,6 @@ static int run_chunk_host(sdrxgpu_bank *b, size_t in_len, void *iq_out, void *au
             HIPCHK(rows_out(iq_out, b->d_keep, sizeof(float2)));
         }
         if (audio_out) {
-            // (calls that take both: the audio rows go by a copy stream of their own -- a copy is set up while the other stream's
-            // runs, and the 10 us between two copies of one stream are gone; they share the link, the bytes are the same)
-            if (n_parts > 1 && iq_out && SDRX_LAB_TWO_COPY_STREAMS) cs = b->copy_stream2;
             if (n_parts > 1) HIPCHK(hipStreamWaitEvent(cs, b->ev_part[p], 0));
             HIPCHK(rows_out(audio_out, b->d_audio_keep, sizeof(float)));
         }
@@ -2828,8 +2810,6 @@ static int run_chunk_host(sdrxgpu_bank *b, size_t in_len, void *iq_out, void *au
     if (n_parts > 1) {      // the keep buffers are free again (next chunk, next call) once the copies have read them
         HIPCHK(hipEventRecord(b->ev_d2h, b->copy_stream));
         HIPCHK(hipStreamWaitEvent(b->stream, b->ev_d2h, 0));
-        HIPCHK(hipEventRecord(b->ev_d2h2, b->copy_stream2));
-        HIPCHK(hipStreamWaitEvent(b->stream, b->ev_d2h2, 0));
     }
     *produced = (size_t)n_b;
     return SDRXGPU_OK;
