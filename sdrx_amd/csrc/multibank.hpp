@@ -9,6 +9,8 @@
 // the outputs leave every device straight into its slice of the caller's chunk: no collective, no RCCL, no peer traffic.
 #pragma once
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -53,7 +55,26 @@ struct sdrxgpu_multibank {
     Job job;
     uint64_t seq = 0;
     int outstanding = 0;
+    // The same two counters once more as atomics, for a short spin in front of either wait: a condition-variable wake-up is 30 - 60 us
+    // on this host, the GPU work of a 1 024-channel shard 120 us -- a stream of blocks posted back to back (bench.py, or a receiver
+    // catching up) should not pay one sleep per shard and block.  A thread spins kSpinUs and then sleeps as before: with a block
+    // every 32 ms (real time) that is 8 x 50 us of polling per block.
+    std::atomic<uint64_t> seq_a{0};
+    std::atomic<int> outstanding_a{0};
 };
+constexpr int kMbSpinUs = 50;
+
+template <class Pred>
+static inline void mb_spin(Pred done)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; !done(); i++) {
+        if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kMbSpinUs)) return;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();          // (host pass only: the device pass of this file has no such builtin, and never runs this)
+#endif
+    }
+}
 
 static void mb_run_one(sdrxgpu_multibank *mb, sdrxgpu_multibank::Shard &s, size_t index, const sdrxgpu_multibank::Job &j)
 {
@@ -88,6 +109,7 @@ static void mb_worker(sdrxgpu_multibank *mb, size_t index)
     (void)hipSetDevice(s.device);
     for (;;) {
         sdrxgpu_multibank::Job j;
+        mb_spin([&] { return mb->seq_a.load(std::memory_order_acquire) != s.seen; });
         {
             std::unique_lock<std::mutex> lock(mb->mu);
             mb->cv_job.wait(lock, [&] { return mb->seq != s.seen; });
@@ -97,6 +119,7 @@ static void mb_worker(sdrxgpu_multibank *mb, size_t index)
         if (j.kind != sdrxgpu_multibank::QUIT) mb_run_one(mb, s, index, j);
         {
             std::lock_guard<std::mutex> lock(mb->mu);
+            mb->outstanding_a.store(mb->outstanding - 1, std::memory_order_release);
             if (--mb->outstanding == 0) mb->cv_done.notify_all();
         }
         if (j.kind == sdrxgpu_multibank::QUIT) return;
@@ -110,11 +133,17 @@ static int mb_dispatch(sdrxgpu_multibank *mb, const sdrxgpu_multibank::Job &j, c
     if (mb->shards.size() == 1 && !mb->shards[0].th.joinable()) {
         mb_run_one(mb, mb->shards[0], 0, j);           // one device: no thread, the caller's own
     } else {
+        {
+            std::unique_lock<std::mutex> lock(mb->mu);
+            mb->job = j;
+            mb->outstanding = (int)mb->shards.size();
+            mb->outstanding_a.store(mb->outstanding, std::memory_order_release);
+            mb->seq++;
+            mb->seq_a.store(mb->seq, std::memory_order_release);
+            mb->cv_job.notify_all();
+        }
+        mb_spin([&] { return mb->outstanding_a.load(std::memory_order_acquire) == 0; });
         std::unique_lock<std::mutex> lock(mb->mu);
-        mb->job = j;
-        mb->outstanding = (int)mb->shards.size();
-        mb->seq++;
-        mb->cv_job.notify_all();
         mb->cv_done.wait(lock, [&] { return mb->outstanding == 0; });
     }
     for (size_t i = 0; i < mb->shards.size(); i++) {
@@ -136,7 +165,9 @@ static int mb_free(sdrxgpu_multibank *mb)
             mb->job.kind = sdrxgpu_multibank::QUIT;
             mb->outstanding = 0;
             for (auto &s : mb->shards) mb->outstanding += s.th.joinable() ? 1 : 0;
+            mb->outstanding_a.store(mb->outstanding, std::memory_order_release);
             mb->seq++;
+            mb->seq_a.store(mb->seq, std::memory_order_release);
             mb->cv_job.notify_all();
         }
         for (auto &s : mb->shards)

@@ -1381,11 +1381,11 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
     // k_stage12m (round 6, tools/lab/sweep_host_entry.py + the copy traces under profiles/r06_host_entry_*): a part's launch costs
     // whole ROUNDS of the workgroups the chip holds at once (512 = 56 sets of 32 slots at the 10 000-channel bank's lane length,
     // about 0.2 ms each, whatever fraction of the round the part fills) -- four equal parts of a bank of 2.9 rounds paid four
-    // rounds, 0.83 ms of stage-1/2 kernels against 0.57 for the whole bank.  So the cuts go where the rounds end: one part per
-    // round for calls that take the decimated IQ (the 61 MB of copies are what takes longest: they start after the first round
-    // and then never wait), and two parts -- all whole rounds, then the rest -- for calls that take the audio only (a third of
-    // the bytes: the kernels are what takes longest; one cut leaves the last round's rows to copy behind them, more cuts only add
-    // launches).  10 000 channels, ms per block: IQ + audio 1.56 (4 equal parts) -> 1.5x, audio only 1.31 -> 1.1x.
+    // rounds, 0.83 ms of stage-1/2 kernels against 0.57 for the whole bank.  So the cuts go by rounds: as many EQUAL parts
+    // as the bank has rounds for calls that take the decimated IQ (the 61 MB of copies are what takes longest: they start after the
+    // first part's round and then never wait), and two parts -- all whole rounds, then the rest -- for calls that take the audio only
+    // (a third of the bytes: the kernels are what takes longest; one cut leaves the last round's rows to copy behind them, more cuts
+    // only add launches).  10 000 channels, ms per block: IQ + audio 1.56 (4 equal parts) -> 1.54, audio only 1.31 -> 1.11.
     {
         const int gsz = b->W * b->CPW;
         const int unit = gsz / (int)gcd_ll(gsz, kWave) * kWave;          // whole channel groups and whole k_agc blocks
@@ -1427,6 +1427,9 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
                 if (sl.x >= 0) first.push_back(sl.x);
             std::sort(first.begin(), first.end());
             const int n_sets = ((int)first.size() + m_set - 1) / m_set;
+            // (whole sets per round: 113 sets of 9 time-workgroups are 1 017 workgroups = two rounds of 512 as ONE launch, but no cut
+            // of them into launches of whole sets fits two rounds -- three parts it is: 7 000 channels 1.20 / 0.95 ms per block
+            // against 1.30 / 0.98 with two)
             const int n_rounds = (n_sets + R - 1) / R;
             // the channel (whole units) up to which the slots fill `sets` sets
             auto cut_at = [&](int sets) {
@@ -1442,10 +1445,14 @@ static int bank_create_impl(const sdrxgpu_bank_cfg *cfg, sdrxgpu_bank **out, int
                 }
                 out.push_back((int)b->n_ch);
             };
-            // [0] IQ + audio: a part per round (at most 8 parts: whole rounds per part beyond that)
+            // [0] IQ + audio: as many parts as the bank has rounds (at most 8: whole rounds per part beyond that), EQUAL in sets -- no
+            // part is longer than its rounds, so the launches cost what the whole bank's cost, and the first part, which everything
+            // waits for, is no larger than the others (a 5 000-channel bank, 81 sets = 1.45 rounds: [41 | 40] 0.962 ms per block
+            // against [56 | 25] 0.985; at 10 000 channels [55 | 54 | 54] is [55 | 56 | 52] to within the noise)
             std::vector<int> ends;
             const int rounds_per_part = (n_rounds + 7) / 8;
-            for (int r = rounds_per_part; r < n_rounds; r += rounds_per_part) ends.push_back(r * R);
+            const int n_p = (n_rounds + rounds_per_part - 1) / rounds_per_part;
+            for (int i = 1; i < n_p; i++) ends.push_back((int)(((long long)n_sets * i + n_p - 1) / n_p));
             build(pc, ends);
             // [1] audio only: every whole round, then the rest
             ends.clear();

@@ -115,7 +115,8 @@ def test_automatic_cuts_follow_the_rounds_and_small_banks_stay_whole(oracle):
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     if n_cu == 256:      # 512 workgroup places / 9 time-workgroups per set = 56 sets of 32 slots per round; 163 sets = 3 rounds
         assert len(with_iq) - 1 == 3 and len(audio_only) - 1 == 2
-        assert audio_only[1] == with_iq[2]                        # "all whole rounds | the rest" ends where the second round ends
+        # calls with IQ: three parts equal in sets (54 / 55 each, no part longer than a round); audio only: two whole rounds | the rest
+        assert audio_only[1] >= with_iq[2] and abs((with_iq[2] - with_iq[1]) - (with_iq[1] - with_iq[0])) <= 1024
     assert len(audio_only) <= len(with_iq)
     # one block through both kinds of call against the oracle on a few channels of every part
     x = synth.synth_iq(9, 0, ch.block_len, 0.25, [tabs[650]], [0.2], ch.N, 10000)
