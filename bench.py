@@ -987,7 +987,7 @@ def main():
             res[label]["d2h_gbs"] = nbytes / (res[label]["ms_per_block"] * 1e-3) / 1e9
         host_path = {"what": f"sdrxgpu_bank_process: {L * 8 / 1e6:.2f} MB H2D + {n_ch * 512 * 12 / 1e6:.1f} MB D2H per block "
                              f"({n_ch * 512 * 4 / 1e6:.1f} MB audio-only), outputs complete on return; the bank runs in channel "
-                             f"parts cut where the rounds of the stage-1/2 kernel end, so that the D2H of one part overlaps the kernels of the next",
+                             f"parts cut by the rounds of the stage-1/2 kernel (sdrxgpu_bank_get_host_parts), so that the D2H of one part overlaps the kernels of the next",
                      "channel_parts": cuts, "d2h_gbs_is": "output bytes / whole call time (the copies alone run at 55 - 56 GB/s: the committed copy trace)",
                      "unit": "Mch-samples/s", **res}
 
