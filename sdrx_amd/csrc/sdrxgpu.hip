@@ -2775,7 +2775,11 @@ static int run_chunk_host(sdrxgpu_bank *b, size_t in_len, void *iq_out, void *au
     if (rc || !job.valid) return rc;
     const int n_b = job.t.n_b;
     const bool copies = n_b > 0 && (iq_out || audio_out);
-    b->cur_plan = iq_out ? 0 : 1;                            // which cut of the bank: bank_create's host-parts comment
+    struct PlanScope {                                       // which cut of the bank (bank_create's host-parts comment), for this chunk only
+        sdrxgpu_bank *b;
+        ~PlanScope() { b->cur_plan = 0; b->mark_after_tail = nullptr; }
+    } plan_scope{b};
+    b->cur_plan = iq_out ? 0 : 1;
     const int n_all = (int)b->plan[b->cur_plan].ch.size() - 1;
     const int n_parts = copies ? n_all : 1;                  // (nothing to copy out: one launch over the whole bank)
     if (n_parts > 1 && (rc = ensure_copy_stream(b))) return rc;
@@ -2813,7 +2817,6 @@ static int run_chunk_host(sdrxgpu_bank *b, size_t in_len, void *iq_out, void *au
             HIPCHK(rows_out(audio_out, b->d_audio_keep, sizeof(float)));
         }
     }
-    b->cur_plan = 0;
     if (n_parts > 1) {      // the keep buffers are free again (next chunk, next call) once the copies have read them
         HIPCHK(hipEventRecord(b->ev_d2h, b->copy_stream));
         HIPCHK(hipStreamWaitEvent(b->stream, b->ev_d2h, 0));
