@@ -8,9 +8,11 @@ kinds of inline assembly whose hazards it cannot see, and whose spacing so far r
       bytes reads its data registers late; a VALU instruction that overwrites them needs 2 wait states behind the store.  (Round 5
       lost one set of a 2 304-channel bank to this before the `s_nop 1` went into the asm statement.)
   R2  `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0] neg_lo|neg_hi` (the P -+ Q combinations behind the f32 MFMAs): a VALU read of a
-      register an MFMA writes needs, for the 8-pass v_mfma_f32_16x16x4_f32 on gfx950, 12 wait states between the two (8 passes + 3,
-      + 1 on gfx950: LLVM's GFX940_XDL_N_PassWriteVgprVALUMemExpReadWaitStates); the kernels rely on the next phase's operand reads
-      standing in between, and on `s_nop 7; s_nop 3` where there are none.
+      register an MFMA writes needs wait states between the two.  For the 8-pass v_mfma_f32_16x16x4_f32 the compiler spaces its OWN
+      such reads by 10 (k_stage12m6's compiler-generated combinations: `s_setprio 0; s_nop 8` = 1 + 9 between the MFMA and the
+      v_sub_f32 that reads it); the kernels' inline assembly was written to 12 (8 passes + 3, + 1 for gfx950: the XDL row of LLVM's
+      GFX940_*_PassWriteVgprVALUMemExpReadWaitStates), and 12 is what the lint asks for.  The kernels rely on the next phase's
+      operand reads standing in between, and on `s_nop 7; s_nop 3` where there are none.
 
 Both are checked on the DISASSEMBLY, over the control-flow graph of every kernel (a wait state is counted only if it lies on every
 path): the lint walks back from each inline v_pk_add_f32 to the nearest v_mfma that writes one of its sources, and forward from each
