@@ -69,8 +69,8 @@ class Ins:
         # destination = first operand of a VALU / MFMA instruction (v_cmp & co. write SGPRs / VCC: no VGPR named there)
         self.dst = regs(parts[0]) if parts and op.startswith("v_") else set()
         self.src = regs(",".join(parts[1:])) if op.startswith("v_") else regs(args)
-        if op.startswith("v_") and ("v_pk_fma" in op or "v_fma" in op or "v_mfma" in op or "v_mac" in op or "v_fmac" in op):
-            self.src |= self.dst if op.startswith(("v_fmac", "v_mac")) else set()
+        if op.startswith(("v_fmac", "v_mac")):
+            self.src |= self.dst                       # (the accumulator is read as well as written)
         self.target = None
         if op.startswith(("s_cbranch", "s_branch")):
             m = _target.search(tail)
