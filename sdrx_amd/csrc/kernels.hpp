@@ -1632,8 +1632,15 @@ __device__ __forceinline__ void if_agc_step(const float2 x, float &g, float &pw,
     // the FMAs are written out (and contraction is off) so that the instruction sequence does not depend on what the
     // surrounding code looks like to the compiler: these are the contractions hipcc chose for the round-1 kernel
 #pragma clang fp contract(off)
-    yr = x.x * g;
-    yi = x.y * g;
+    // Two of the step's pairs of equal operations go out as ONE packed instruction each (round 6): x g for both components
+    // (v_pk_mul_f32, the gain taken for both halves by op_sel) and the two candidate gain updates (v_pk_fma_f32 on (decay, attack)).
+    // The same IEEE operations on the same operands -- the same bits (tools/lab/hash_outputs.py) -- in 9 instructions per step instead
+    // of 11: the wave that runs this chain has its SIMD to itself, and what it pays for is instructions (a shorter chain of MORE
+    // instructions was slower, profiles/r06_agc_lab_ab.txt): k_agc 24.9 -> 23.3 us, the 64-channel block 0.0443 -> 0.0427 ms.
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    const v2f_ y = v2f_{x.x, x.y} * v2f_{g, g};
+    yr = y.x;
+    yi = y.y;
     nrm = __builtin_fmaf(yr, yr, yi * yi);
     pw = __builtin_fmaf(A.alpha, nrm - pw, pw);
     const float err = A.reference - pw;
@@ -1642,7 +1649,8 @@ __device__ __forceinline__ void if_agc_step(const float2 x, float &g, float &pw,
     // (err > 0: err * decay <= err * attack; err < 0: the other way round, and the reference takes attack; err = 0: both are g) -- the
     // larger one with decay > attack.  v_med3_f32 against -inf / +inf (A.sel, set on the host) is that min / max: the same bits, and
     // compare -> select -> fma on the recurrence's critical path becomes two independent fmas -> med3 (k_agc 25.5 -> 24.0 us).
-    g = __builtin_amdgcn_fmed3f(__builtin_fmaf(err, A.decay, g), __builtin_fmaf(err, A.attack, g), A.sel);
+    const v2f_ gg = __builtin_elementwise_fma(v2f_{err, err}, v2f_{A.decay, A.attack}, v2f_{g, g});
+    g = __builtin_amdgcn_fmed3f(gg.x, gg.y, A.sel);
     g = __builtin_amdgcn_fmed3f(g, A.min_gain, A.max_gain);      // the clamp of agc.hpp:63-67 in one instruction
 }
 
@@ -1673,7 +1681,9 @@ __device__ __forceinline__ float demod_lf_step(float yr, float yi, float nrm, fl
 #pragma clang fp contract(off)
         pl = __builtin_fmaf(Lf.alpha, __builtin_fmaf(sl, sl, -pl_), pl_);   // (sl*sl - power is one rounding, as hipcc contracted it in round 1)
         const float errl = Lf.reference - __builtin_amdgcn_sqrtf(pl);
-        gl = __builtin_amdgcn_fmed3f(__builtin_fmaf(errl, Lf.decay, gl_), __builtin_fmaf(errl, Lf.attack, gl_), Lf.sel);   // (as if_agc_step)
+        typedef float v2f_ __attribute__((ext_vector_type(2)));
+        const v2f_ gg = __builtin_elementwise_fma(v2f_{errl, errl}, v2f_{Lf.decay, Lf.attack}, v2f_{gl_, gl_});   // (one v_pk_fma_f32, as if_agc_step)
+        gl = __builtin_amdgcn_fmed3f(gg.x, gg.y, Lf.sel);
     }
     gl = __builtin_amdgcn_fmed3f(gl, Lf.min_gain, Lf.max_gain);
     float out = lf_active ? sl : s;
